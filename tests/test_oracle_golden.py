@@ -1,0 +1,111 @@
+"""CPU: the oracle (oracle/parrot_oracle.py) must reproduce, BIT-EXACTLY, the vectors captured from
+the reference implementation by tools/make_goldens.py (tests/golden/*.npz), after regenerating
+the same seeded synthetic checkpoints (digest-checked)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import parrot_oracle as O
+from parrot_tts_amd import synth
+
+torch.set_num_threads(8)
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(z["meta"])) if "meta" in z.files else {}
+    return z, meta
+
+
+TTE_CASES = {
+    "tte_full_ragged": synth.default_tte_config,
+    "tte_full_forced": synth.default_tte_config,
+    "tte_small_ragged": synth.small_tte_config,
+    "tte_small_multi": synth.small_tte_config,
+}
+
+
+@pytest.mark.parametrize("name", list(TTE_CASES))
+def test_tte_oracle_matches_reference(golden_dir, name):
+    z, m = _load(golden_dir, name)
+    cfg = TTE_CASES[name]()
+    sd = synth.synth_tte_state_dict(cfg, m["vocab"], m["n_spk"], seed=m["seed_w"], forced_duration=m["forced"], gain=m["gain"])
+    assert synth.state_digest(sd) == str(z["digest"]), "synthetic weights did not regenerate identically"
+    batch = {"phones": torch.from_numpy(z["phones"]), "src_mask": torch.from_numpy(z["src_mask"]),
+             "speaker": torch.from_numpy(z["speaker"])}
+    gen = synth.synth_tte_batch(m["B"], m["S"], m["vocab"], m["n_spk"], seed=m["seed_in"], ragged=m["ragged"])
+    assert torch.equal(gen["phones"], batch["phones"])
+    with torch.no_grad():
+        r = O.tte_forward(sd, cfg, batch)
+        ids_ragged = O.tte_infer(sd, cfg, batch)
+    assert np.array_equal(r["log_dur"].numpy(), z["log_dur"])
+    assert np.array_equal(r["dur"].numpy(), z["dur"])
+    assert np.array_equal(r["tgt_mask"].numpy(), z["tgt_mask"])
+    assert np.array_equal(torch.argmax(r["logits"], -1).numpy(), z["ids"])
+    n = z["logits_head"].shape[0]
+    assert np.array_equal(r["logits"][:n].numpy(), z["logits_head"])
+    for b, row in enumerate(ids_ragged):
+        ln = int(z["ids_ragged_len"][b])
+        assert row == z["ids_ragged"][b, :ln].tolist()
+    # quirk Q2: every row emits len+1 ids except rows of maximal length
+    L = r["logits"].shape[1]
+    for b, row in enumerate(ids_ragged):
+        assert len(row) == min(r["lens"][b] + 1, L)
+
+
+def test_tte_blocks(golden_dir):
+    z, _ = _load(golden_dir, "tte_blocks")
+    cfg = synth.default_tte_config()
+    sd = synth.synth_tte_state_dict(cfg, 50, 2, seed=7)
+    assert synth.state_digest(sd) == str(z["digest"])
+    x, kpm = torch.from_numpy(z["x"]), torch.from_numpy(z["kpm"])
+    with torch.no_grad():
+        y = O.fft_block(sd, "decoder_layers.1.", x, 2, [9, 1], kpm)
+        ld = O.duration_predictor(sd, x, kpm, 3)
+        ex, tm, _ = O.length_regulator(torch.from_numpy(z["lr_seq"]), torch.from_numpy(z["lr_dur"]))
+    assert np.array_equal(y.numpy(), z["fft_out"])
+    assert np.array_equal(ld.numpy(), z["log_dur"])
+    assert np.array_equal(ex.numpy(), z["lr_out"])
+    assert np.array_equal(tm.numpy(), z["lr_mask"])
+
+
+def _voc_cfg(name):
+    if name.startswith("voc_full"):
+        return synth.default_voc_config()
+    h = synth.small_voc_config()
+    if name == "voc_small_singlespk":
+        h["multispkr"] = None
+        h["model_in_dim"] = h["embedding_dim"]
+    if name == "voc_small_resblock2":
+        h["resblock"] = "2"
+        h["resblock_dilation_sizes"] = [[1, 3], [1, 3], [1, 3]]
+    return h
+
+
+VOC_CASES = ["voc_full_stages", "voc_full_u40", "voc_full_u40_hot", "voc_small", "voc_small_singlespk",
+             "voc_small_resblock2", "voc_full_u256"]
+
+
+@pytest.mark.parametrize("name", VOC_CASES)
+def test_vocoder_oracle_matches_reference(golden_dir, name):
+    z, m = _load(golden_dir, name)
+    h = _voc_cfg(name)
+    sd = synth.synth_voc_state_dict(h, seed=m["seed_w"], scale=m["scale"])
+    assert synth.state_digest(sd) == str(z["digest"])
+    code, spkr = torch.from_numpy(z["code"]), torch.from_numpy(z["spkr"])
+    st = {}
+    with torch.no_grad():
+        y = O.code_generator_forward(sd, h, code, spkr, stages=st)
+        y_folded = O.code_generator_forward(O.fold_weight_norm(sd), h, code, spkr)
+    assert y.shape == (m["B"], 1, m["U"] * int(np.prod(h["upsample_rates"])))
+    assert np.array_equal(y.numpy(), z["wav"])
+    assert np.array_equal(y_folded.numpy(), z["wav"]), "weight_g/weight_v and folded checkpoints must agree"
+    assert np.array_equal(O.to_int16(y.squeeze(1)), z["wav_int16"])
+    for k in z.files:
+        if k.startswith("stage_"):
+            assert np.array_equal(st[k[6:]].numpy(), z[k]), k
+    if "wav_fp64" in z.files:  # the reference's own fp32 round-off at realistic scale
+        assert np.abs(z["wav"] - z["wav_fp64"]).max() < 5e-5
