@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- Parrot-TTS synthesis throughput on MI355X (BASELINE.json metric: audio samples/s + RTF
+for batch-64 x 256-unit inputs).
+
+One "step" = one pass of the hot path over one batch of synthetic input per GPU:
+    TTE (S=64 tokens -> forced duration 4 -> L=256 units) -> HiFi-GAN generator (256 units -> 81 920 samples)
+with inputs already resident in HBM.  N>1: one process per GPU (torchrun contract), utterances
+sharded by batch row (weak scaling, per-GPU batch fixed), one RCCL gather of the waveforms to rank 0
+per step.  Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from parrot_tts_amd import _lib, synth  # noqa: E402
+from parrot_tts_amd import dist as pdist  # noqa: E402
+from parrot_tts_amd.pipeline import SynthesisPipeline  # noqa: E402
+from parrot_tts_amd.tte import Parrot  # noqa: E402
+from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+HBM_PEAK_GBS = 8000.0
+SAMPLE_RATE = 16000             # reference utils/vocoder/config.json:32 (the metric's "22.05 kHz" does not match the reference)
+TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16>", "conv_mfma_kernel<1,4,2,2,16>", "conv_mfma_kernel<1,4,1,4,16>",
+              "conv_mfma_kernel<2,2,2,2,32>", "conv_mfma_kernel<2,2,2,1,16>"]
+
+
+def build_models(dev, vocab=300, n_spk=10):
+    cfg, h = synth.default_tte_config(), synth.default_voc_config()
+    tmp = tempfile.mkdtemp()
+    cfg["path"]["root_path"] = tmp
+    with open(os.path.join(tmp, "speakers.json"), "w") as f:
+        json.dump({f"spk{i}": i for i in range(n_spk)}, f)
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=42, forced_duration=4)
+    vsd = synth.synth_voc_state_dict(h, seed=1234, scale=1.0)
+    parrot = Parrot(cfg, vocab, 0)
+    parrot.load_state_dict(tsd)
+    gen = CodeGenerator(AttrDict(h))
+    gen.load_state_dict(vsd)
+    gen.eval()
+    gen.remove_weight_norm()  # as reference utils/vocoder/inference.py:136-137
+    return cfg, h, tsd, vsd, parrot.eval().to(dev), gen.to(dev)
+
+
+def cpu_baseline(cfg, h, tsd, vsd, B, S, vocab, n_spk):
+    """The oracle (CPU restatement, parity-pinned to the reference) timed on this host's cores on a bounded
+    sample of the same workload: B utterances of the full pipeline."""
+    from oracle import parrot_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=0)
+    folded = O.fold_weight_norm(vsd)
+
+    def run():
+        with torch.no_grad():
+            r = O.tte_forward(tsd, cfg, batch)
+            ids = torch.argmax(r["logits"], -1)
+            return O.code_generator_forward(folded, h, ids, batch["speaker"].reshape(-1, 1))
+
+    run()
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        y = run()
+        ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    n = y.shape[0] * y.shape[-1]
+    return {"value": n / best, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle full pipeline (TTE S={S}->L={y.shape[-1] // 320} + HiFi-GAN), batch {B}, fp32, torch-CPU {cores} threads, "
+                      f"best of 2 after 1 warm-up ({best:.2f} s/pass)",
+            "rtf": best / (n / SAMPLE_RATE)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--src-len", type=int, default=64)
+    ap.add_argument("--workload", choices=["full", "vocoder"], default="full")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = pdist.init_from_env("nccl")
+    if world != a.gpus:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    vocab, n_spk = 300, 10
+    cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
+    pipe = SynthesisPipeline(parrot, gen)
+    B, S = a.batch, a.src_len
+    batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(B, S, vocab, n_spk, seed=rank).items()}
+    vb = {k: v.to(dev) for k, v in synth.synth_voc_batch(B, 4 * S, h, seed=rank).items()}
+
+    def step():
+        if a.workload == "full":
+            out = pipe(batch)
+            wav = out["wav"]
+        else:
+            wav = gen(code=vb["code"], spkr=vb["spkr"])
+        return pdist.gather_waveforms(wav, dst=0) if world > 1 else wav
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        wav = step()
+    fence()
+    lib = _lib.lib()
+    lib.parrot_prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wav = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = (C.c_double * (4 * len(TILE_NAMES)))()
+    _lib.check(lib.parrot_prof_end(prof, len(TILE_NAMES)))
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        n_samples_step = world * B * (wav.shape[-1] if wav is not None else 0)
+        ms = elapsed / a.steps * 1e3
+        value = n_samples_step / (ms / 1e3)
+        rows = []
+        for i, nm in enumerate(TILE_NAMES):
+            n, tms, fl, by = prof[4 * i: 4 * i + 4]
+            if n > 0:
+                rows.append({"kernel": nm, "launches_per_step": n / a.steps, "avg_us": tms / n * 1e3, "ms_per_step": tms / a.steps,
+                             "tflops": fl / tms / 1e9, "alg_gbs": by / tms / 1e6})
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        dom = rows[0]
+        roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_us": dom["avg_us"],
+                "launches_per_step": dom["launches_per_step"], "alg_GBps": dom["alg_gbs"], "all_conv_kernels": rows}
+        res = {
+            "metric": "audio samples/sec (16 kHz; see config.note) + RTF, 256-unit batch-64 per GPU",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf": (ms / 1e3) / (n_samples_step / SAMPLE_RATE),
+            "config": {"workload": ("full TTE(S=%d)->length-regulator(L=%d)->HiFi-GAN(%d samples/utt)" % (S, 4 * S, 4 * S * 320))
+                       if a.workload == "full" else "HiFi-GAN generator only, %d units" % (4 * S),
+                       "per_gpu_batch": B, "global_batch": world * B, "units_per_utt": 4 * S, "sample_rate": SAMPLE_RATE,
+                       "parallelism": f"dp{world} (batch shard, RCCL waveform gather)",
+                       "weights": "seeded synthetic, reference checkpoint layouts (TTE seed 42 forced duration 4; vocoder seed 1234)",
+                       "note": "reference vocoder is 16 kHz / 320 samples per unit (utils/vocoder/config.json:24,32), not 22.05 kHz"},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, h, tsd, vsd, a.cpu_batch, S, vocab, n_spk)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

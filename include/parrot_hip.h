@@ -1,0 +1,188 @@
+/*
+ * parrot_hip.h -- C ABI of libparrot_hip.so: the MI355X (gfx950) implementation of the
+ * Parrot-TTS synthesis hot path (TTE -> length regulator -> HiFi-GAN unit vocoder).
+ *
+ * The reference (parrot-tts/Parrot-TTS) is pure Python on torch.nn and has no FFI of its own;
+ * the seam this library plugs into is the nn.Module surface the reference drivers call.  Each
+ * entry point below names the reference code it replaces (paths relative to the reference
+ * repo).  The Python shims in parrot_tts_amd/ (tte.py, vocoder.py) bind these with ctypes --
+ * see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; no torch / C++ types cross the boundary
+ *   - return 0 on success, a negative PARROT_E_* code otherwise; parrot_last_error() gives a
+ *     thread-local message; no C++ exception crosses the ABI
+ *   - weights are HOST pointers (fp32, row-major, already weight-norm-folded): *_create packs them
+ *     into MFMA fragment order and uploads them once; the handle owns that device copy
+ *   - activations / ids / outputs are DEVICE pointers allocated by the caller (PyTorch's caching
+ *     allocator); the library never allocates per call: callers pass a workspace sized by
+ *     *_workspace_bytes().  All launches are asynchronous on the hipStream_t passed (as void*)
+ *   - one process per GPU; a handle is bound to the device current at *_create
+ */
+#ifndef PARROT_HIP_H
+#define PARROT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARROT_ABI_VERSION 1
+
+enum {
+    PARROT_OK = 0,
+    PARROT_E_INVALID = -1,     /* bad argument / unsupported dimension                         */
+    PARROT_E_RANGE = -2,       /* T >= max_len (reference: IndexError at modules/fft.py:18)    */
+    PARROT_E_HIP = -3,         /* a HIP runtime call failed                                    */
+    PARROT_E_NOMEM = -4,       /* workspace too small / allocation failed                      */
+    PARROT_E_UNSUPPORTED = -5, /* configuration outside what the kernels cover                 */
+};
+
+int parrot_abi_version(void);
+const char* parrot_last_error(void);
+/* Runs the MFMA fragment-layout probe on the current device (0 = layouts as assumed). */
+int parrot_selftest(void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Single Conv1d / ConvTranspose1d plan: the dilated-Conv1d implicit-GEMM kernel behind every
+ * torch.nn.Conv1d / ConvTranspose1d / Linear on the path
+ *   (utils/vocoder/models.py:17-28,75,81-83,91; modules/fft.py:48-50,65-76; modules/duration.py:64-72).
+ * y[b,o,t] = act(bias[o] + sum_{i,j} w[o,i,j] * pre(x[b,i,t + j*dil - pad])) (+ res[b,o,t])
+ * ------------------------------------------------------------------------------------------ */
+typedef struct parrot_conv parrot_conv_t;
+
+typedef struct {
+    int32_t c_in, c_out, k, dilation, padding; /* Conv1d: symmetric zero padding                 */
+    int32_t transposed;                        /* 1: ConvTranspose1d, weight (c_in,c_out,k)      */
+    int32_t stride;                            /* ConvTranspose1d stride (upsample rate); else 1 */
+    int32_t pre_act;                           /* 0 none, 1 leaky_relu(pre_slope) on the input   */
+    float pre_slope;
+    int32_t act;                               /* 0 none, 1 relu, 2 tanh (applied to bias+sum)   */
+    int32_t tile_cfg;                          /* -1 = auto; else index into the tile table      */
+} parrot_conv_desc;
+
+int parrot_conv_create(parrot_conv_t** out, const parrot_conv_desc* d, const float* w_host, const float* bias_host);
+void parrot_conv_destroy(parrot_conv_t*);
+/* epilogue: 0 store, 1 y += v, 2 y = (y + v) / div  (MRF sum, models.py:100-106) */
+int parrot_conv_run(parrot_conv_t*, const float* x, const float* res, float* y, int32_t B, int32_t T_in,
+                    int32_t epilogue, float div, void* stream);
+int parrot_conv_out_len(const parrot_conv_t*, int32_t T_in);
+int parrot_conv_num_tile_cfgs(void);
+
+/* Optional per-launch timing of the conv kernel with HIP events on the launch stream, aggregated
+ * per tile configuration (bench.py's roofline object).  prof_end fills out[cfg*4 + {0..3}] =
+ * {launches, total ms, algorithmic FLOPs, algorithmic bytes} for n_cfg configurations.         */
+int parrot_prof_begin(void);
+int parrot_prof_end(double* out, int32_t n_cfg);
+
+/* ------------------------------------------------------------------------------------------
+ * HiFi-GAN unit vocoder: CodeGenerator.forward (utils/vocoder/models.py:153-169) ->
+ * Generator.forward (:95-111) with ResBlock1/2 (:31-38,:58-62).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct parrot_voc parrot_voc_t;
+
+#define PARROT_MAX_STAGES 8
+#define PARROT_MAX_KERNELS 4
+#define PARROT_MAX_DIL 4
+
+typedef struct {
+    int32_t num_embeddings, embedding_dim; /* h.num_embeddings, h.embedding_dim                 */
+    int32_t multispkr, n_spkr;             /* bool(h.multispkr); spkr table rows (10)           */
+    int32_t model_in_dim;                  /* conv_pre input channels                           */
+    int32_t upsample_initial_channel;
+    int32_t n_stages;
+    int32_t upsample_rates[PARROT_MAX_STAGES];
+    int32_t upsample_kernel_sizes[PARROT_MAX_STAGES];
+    int32_t n_kernels;
+    int32_t resblock_kernel_sizes[PARROT_MAX_KERNELS];
+    int32_t n_dil;
+    int32_t resblock_dilation_sizes[PARROT_MAX_KERNELS][PARROT_MAX_DIL];
+    int32_t resblock_type;                 /* 1 = ResBlock1, 2 = ResBlock2 (h.resblock)         */
+} parrot_voc_cfg;
+
+/* Folded fp32 weights on the HOST, torch layouts.  resblock conv index:
+ *   ResBlock1: [(stage*n_kernels + j)*2*n_dil + m*2 + {0: convs1[m], 1: convs2[m]}]
+ *   ResBlock2: [(stage*n_kernels + j)*n_dil + m]                                              */
+typedef struct {
+    const float* dict;      /* (num_embeddings, embedding_dim)  */
+    const float* spkr;      /* (n_spkr, embedding_dim) or NULL  */
+    const float* conv_pre_w; const float* conv_pre_b;   /* (C0, model_in_dim, 7), (C0)          */
+    const float* ups_w[PARROT_MAX_STAGES];               /* (C_in, C_in/2, k)                    */
+    const float* ups_b[PARROT_MAX_STAGES];
+    const float* const* rb_w;                            /* array of (C, C, k) pointers          */
+    const float* const* rb_b;
+    int32_t n_rb;
+    const float* conv_post_w; const float* conv_post_b; /* (1, C_last, 7), (1)                  */
+} parrot_voc_weights;
+
+int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w);
+void parrot_voc_destroy(parrot_voc_t*);
+size_t parrot_voc_workspace_bytes(const parrot_voc_t*, int32_t B, int32_t U);
+/* code (B,U) int64, spkr (B,1) int64 or NULL -> wav (B,1,U*prod(rates)) fp32 in (-1,1).
+ * stage_out: optional array of 2*n_stages+1 device pointers (conv_pre, ups_i, mrf_i ...) that
+ * receive copies of the intermediate activations (tests only); NULL in production.            */
+int parrot_voc_forward(parrot_voc_t*, const int64_t* code, const int64_t* spkr, int32_t B, int32_t U,
+                       float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream);
+int parrot_voc_check(parrot_voc_t*, void* stream);
+/* wav (n) fp32 -> int16 as `(x*32768).astype('int16')` does (utils/vocoder/inference.py:71-73) */
+int parrot_wav_to_int16(const float* wav, int16_t* out, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TTE: Parrot.forward(inference=True) / Parrot.infer  (modules/parrot.py:90-120) with
+ * FFTBlock (modules/fft.py:85-100), DurationPredictor + length_regulator (modules/duration.py),
+ * get_mask_from_lengths (modules/data.py:8-20).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct parrot_tte parrot_tte_t;
+
+typedef struct {
+    int32_t d_model, n_filter_ffn, ffn_k1, ffn_k2, max_len;
+    int32_t enc_layers, enc_heads, dec_layers, dec_heads;
+    int32_t dp_filter, dp_kernel;
+    int32_t vocab, n_speaker /* 0/1 = no speaker_emb */, n_codes /* head width (hubert_codes) */;
+} parrot_tte_cfg;
+
+typedef struct {
+    const float *qkv, *in_proj, *out_proj, *wo;                   /* (3D,D) (3D,D) (D,D) (D,D)  */
+    const float *conv1_w, *conv1_b, *conv2_w, *conv2_b;           /* (F,D,k1) (F) (D,F,k2) (D)  */
+    const float *attn_norm_w, *attn_norm_b, *conv_norm_w, *conv_norm_b;
+} parrot_fft_weights;
+
+typedef struct {
+    const float* pe;         /* (max_len, D)  pos_emb.pe                                        */
+    const float* tok_emb;    /* (vocab, D)                                                       */
+    const float* speaker_emb;/* (n_speaker, D) or NULL                                           */
+    const float *dp_conv0_w, *dp_conv0_b, *dp_ln0_w, *dp_ln0_b;
+    const float *dp_conv1_w, *dp_conv1_b, *dp_ln1_w, *dp_ln1_b;
+    const float *dp_proj_w, *dp_proj_b;
+    const parrot_fft_weights* enc;  /* enc_layers entries */
+    const parrot_fft_weights* dec;  /* dec_layers entries */
+    const float *head_w, *head_b;   /* (n_codes, D), (n_codes) */
+} parrot_tte_weights;
+
+int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w);
+void parrot_tte_destroy(parrot_tte_t*);
+/* `state` carries the encoder output + duration prefix sums from encode to decode (sized by B,S);
+ * `ws` is scratch: encode needs workspace_bytes(B,S,0), decode workspace_bytes(B,S,L).         */
+size_t parrot_tte_state_bytes(const parrot_tte_t*, int32_t B, int32_t S);
+size_t parrot_tte_workspace_bytes(const parrot_tte_t*, int32_t B, int32_t S, int32_t L_max);
+/* Phase 1 (parrot.py:94-102 up to the durations): phones (B,S) i64, src_mask (B,S) u8 1=valid,
+ * speaker (B) i64 or NULL -> log_dur (B,S) f32, dur (B,S) i64, out_lens (B) i32 (sum of dur). */
+int parrot_tte_encode(parrot_tte_t*, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker,
+                      int32_t B, int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens,
+                      void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
+/* Phase 2 (duration.py:6-24, parrot.py:106-108,115): needs L = max(out_lens) from the host
+ * (the reference's own host sync, duration.py:10).  -> ids (B,L) i64 argmax, tgt_mask (B,L) u8
+ * (ids <= len, quirk Q2), optional logits (B,L,n_codes) f32 (tests).                          */
+int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L,
+                      int64_t* ids, uint8_t* tgt_mask, float* logits /* nullable */,
+                      void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
+/* Device-side id-range flag (a bad phone / unit / speaker id <-> the reference's Embedding
+ * IndexError).  Synchronises `stream`; returns 0 or PARROT_E_RANGE and clears the flag.       */
+int parrot_tte_check(parrot_tte_t*, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARROT_HIP_H */

@@ -1,0 +1,264 @@
+// conv_mfma.h -- the dilated Conv1d implicit-GEMM kernel (fp32 in, fp32 accumulate) for gfx950.
+//
+// One kernel family covers every Conv1d / ConvTranspose1d / Linear on the Parrot-TTS hot path
+// (reference utils/vocoder/models.py:17-28,75,81-83,91; modules/fft.py:48-50,65-76;
+// modules/duration.py:64-72).  Layout is channel-first (B, C, T), T contiguous, as in the
+// reference's vocoder.
+//
+//   GEMM view per batch row:  Y[M x N] = W[M x K] * X~[K x N],  M = C_out, N = T, K = C_in*k,
+//   X~[(i,j)][t] = pre(x[i][t + j*dil - pad])  (never materialised: an x slab with halo sits in LDS
+//   and every tap is a shifted ds_read of the same slab).
+//
+// MI355X mapping
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD = the fp32 peak
+//     (157 TF); A and B operands are ONE f32 VGPR per lane, so LDS/L2 operand traffic per MFMA is tiny
+//     and the matrix pipe is the only saturated resource.
+//   * A (weights) never touches LDS: the host packs it into MFMA fragment order, so each wave
+//     streams its 32-row slice with one fully coalesced 1 KiB global_load_dwordx4 per 4 k-steps
+//     (L2-resident: the largest layer is 2.9 MB), register double-buffered one group ahead.
+//   * B (activations): a [CI channels][BN + halo] slab is staged global->reg->(leaky-relu)->LDS with
+//     coalesced 256 B rows, double-buffered in LDS; one barrier per CI-channel chunk.  Within a
+//     k-step the two 32-lane halves of the wave read two adjacent channels at the same tap, so every
+//     ds_read_b32 is 32 consecutive dwords per half: bank-conflict free for every dilation.
+//   * 256-thread workgroups (4 waves), 2 per CU; wave tile 64x64 (2x2 MFMA tiles) or 32x128.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace parrot {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { PRE_NONE = 0, PRE_LRELU = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_ADD_DIV = 2 };
+
+constexpr int CONV_HALO = 64;  // max (k-1)*dil the fast path supports (MRF needs 50)
+
+struct ConvParams {
+    const float* x;      // (B, Cin, Tin)
+    const float* wfrag;  // packed A fragments [mtile][it][lane][4]
+    const float* bias;   // [Cout] or null
+    const float* res;    // (B, Cout, Tout) or null
+    float* y;            // (B, Cout, Tout)
+    int B, Cin, Tin;
+    int M;               // GEMM rows: Cout (conv) or Cout*u (transposed, row = o*u + phase)
+    int Cout;
+    int Ncols;           // GEMM columns per batch row
+    int Tout;            // output length per batch row
+    int k, dil, pad_left;
+    int nchunks;         // ceil(Cin / CI)
+    int n_it;            // nchunks * k * (CI/8): A-fragment groups per m-tile
+    int pre;
+    float pre_slope;
+    int act;
+    int epi;
+    float div;
+    int u;               // transposed stride (1 for plain conv)
+    int tiles_n;
+    long x_bstride;      // elements between batch rows of x / y / res (lets callers address channel slices)
+    long y_bstride;
+    long res_bstride;
+    int groups;          // grouped conv: Cin is PER GROUP, rows [g*Mg, (g+1)*Mg) read channels [g*Cin, (g+1)*Cin)
+    int Mg;              // rows per group (multiple of the block's BM when groups > 1)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// WAVES_M x WAVES_N waves, each owning WM x WN MFMA tiles of 32x32; CI input channels per LDS slab.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int CI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const ConvParams p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * WM * 32;
+    constexpr int BN = WAVES_N * WN * 32;
+    constexpr int RS = BN + CONV_HALO;      // LDS row stride (floats)
+    constexpr int QN = CI / 8;              // A groups (4 k-steps x 2 channels) per tap per chunk
+    constexpr int ROWS_PW = CI / NW;        // slab rows staged by each wave
+    constexpr int COLS_IT = (RS + 63) / 64; // 64-column strips per row
+    static_assert(CI % 8 == 0 && CI % NW == 0, "CI must be a multiple of 8 and of the wave count");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][CI][RS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int b = blockIdx.x / p.tiles_n;
+    const int tn = blockIdx.x - b * p.tiles_n;
+    const int t0 = tn * BN;
+    const int W = BN + (p.k - 1) * p.dil;  // live slab width (<= RS, checked on the host)
+    const int grp = (p.groups > 1) ? (blockIdx.y * BM) / p.Mg : 0;
+    const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride + (size_t)grp * p.Cin * p.Tin;
+
+    float stage[ROWS_PW][COLS_IT];
+
+    auto load_slab = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < ROWS_PW; ++r) {
+            const int ch = c * CI + wave * ROWS_PW + r;
+            const float* __restrict__ row = xb + (size_t)ch * p.Tin;
+#pragma unroll
+            for (int i = 0; i < COLS_IT; ++i) {
+                const int col = lane + 64 * i;
+                const int tin = t0 - p.pad_left + col;
+                float v = 0.f;
+                if (col < W && ch < p.Cin && tin >= 0 && tin < p.Tin) v = row[tin];
+                if (p.pre == PRE_LRELU) v = v > 0.f ? v : v * p.pre_slope;
+                stage[r][i] = v;
+            }
+        }
+    };
+    auto store_slab = [&](int buf) {
+        float* dst = smem + buf * (CI * RS);
+#pragma unroll
+        for (int r = 0; r < ROWS_PW; ++r) {
+#pragma unroll
+            for (int i = 0; i < COLS_IT; ++i) {
+                const int col = lane + 64 * i;
+                if (col < RS) dst[(wave * ROWS_PW + r) * RS + col] = stage[r][i];
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // A-fragment stream: one 1 KiB group (64 lanes x float4) per (chunk, tap, q) per m-tile.
+    const f32x4* __restrict__ aptr[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int mtg = blockIdx.y * (BM / 32) + wm * WM + mt;
+        aptr[mt] = reinterpret_cast<const f32x4*>(p.wfrag) + (size_t)mtg * p.n_it * 64 + lane;
+    }
+    f32x4 a_nxt[WM], a_cur[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) a_nxt[mt] = aptr[mt][0];
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+
+    // per-lane LDS read base: row (half) of the channel pair, column of this lane in the wave's N range
+    const int bbase = half * RS + wn * (WN * 32) + l31;
+    int it = 0;
+    for (int c = 0; c < p.nchunks; ++c) {
+        const float* __restrict__ xs = smem + (c & 1) * (CI * RS) + bbase;
+        const bool more = (c + 1 < p.nchunks);
+        if (more) load_slab(c + 1);
+        for (int j = 0; j < p.k; ++j) {
+            const float* __restrict__ xj = xs + j * p.dil;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                ++it;
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt) {
+                    a_cur[mt] = a_nxt[mt];
+                    a_nxt[mt] = aptr[mt][(size_t)it * 64];  // wfrag is padded by one group at the end
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bv[WN];
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt) bv[nt] = xj[(8 * q + 2 * e) * RS + nt * 32];
+#pragma unroll
+                    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < WN; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][e], bv[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_slab((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const size_t ybase = (size_t)b * p.y_bstride;
+    const size_t rbase = (size_t)b * p.res_bstride;
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const int n = t0 + (wn * WN + nt) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = blockIdx.y * BM + (wm * WM + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M && n < p.Ncols) {
+                    int o = m, tau = n;
+                    if (p.u > 1) {
+                        o = m / p.u;
+                        tau = n * p.u + (m - o * p.u);
+                    }
+                    if (tau < p.Tout) {
+                        float v = acc[mt][nt][r];
+                        if (p.bias) v += p.bias[o];
+                        v = apply_act(v, p.act);
+                        const size_t off = (size_t)o * p.Tout + tau;
+                        const size_t idx = ybase + off;
+                        if (p.res) v += p.res[rbase + off];
+                        if (p.epi == EPI_ADD) v = p.y[idx] + v;
+                        else if (p.epi == EPI_ADD_DIV) v = (p.y[idx] + v) / p.div;
+                        p.y[idx] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// tile table (index = parrot_conv_desc.tile_cfg)
+struct TileCfg {
+    int bm, bn, ci, threads;
+};
+constexpr int NUM_TILE_CFGS = 5;
+__host__ inline TileCfg tile_cfg(int id) {
+    switch (id) {
+        case 0: return {128, 128, 16, 256};  // waves 2x2, wave 64x64
+        case 1: return {64, 256, 16, 256};   // waves 1x4, wave 64x64
+        case 2: return {32, 512, 16, 256};   // waves 1x4, wave 32x128
+        case 3: return {128, 128, 32, 256};  // as 0 with 32-channel slabs (fewer barriers for k<=3)
+        default: return {128, 64, 16, 256};  // waves 2x2, wave 64x32 (short sequences)
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int CI>
+inline hipError_t launch_conv_t(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
+    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, WM, WN, CI>;
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in (gfx950 has 160 KiB per CU)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+inline hipError_t launch_conv(int cfg, const ConvParams& p, hipStream_t s) {
+    const TileCfg t = tile_cfg(cfg);
+    dim3 grid(p.tiles_n * p.B, (p.M + t.bm - 1) / t.bm);
+    const size_t lds = (size_t)2 * t.ci * (t.bn + CONV_HALO) * sizeof(float);
+    switch (cfg) {
+        case 0: return launch_conv_t<2, 2, 2, 2, 16>(p, grid, lds, s);
+        case 1: return launch_conv_t<1, 4, 2, 2, 16>(p, grid, lds, s);
+        case 2: return launch_conv_t<1, 4, 1, 4, 16>(p, grid, lds, s);
+        case 3: return launch_conv_t<2, 2, 2, 2, 32>(p, grid, lds, s);
+        default: return launch_conv_t<2, 2, 2, 1, 16>(p, grid, lds, s);
+    }
+}
+
+}  // namespace parrot

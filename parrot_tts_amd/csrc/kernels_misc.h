@@ -1,0 +1,290 @@
+// kernels_misc.h -- the HBM-bound glue kernels of the Parrot-TTS path (gathers, LayerNorm, softmax,
+// duration rounding, length regulator, argmax).  All activations are channel-first (B, C, T).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace parrot {
+
+// ---------------------------------------------------------------------------------------------
+// vocoder input: x[b, c, t] = c < E ? dict[code[b,t]][c] : spkr[spkr_id[b]][c - E]
+// (utils/vocoder/models.py:155-160 + _upsample :132-151: the speaker vector is repeated over time)
+// grid (ceil(U/64), C/?, B): each block = 64 time steps x 64 channels via an LDS transpose so that
+// both the embedding-row reads (contiguous in c) and the (B,C,U) writes (contiguous in t) coalesce.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __restrict__ code, const int64_t* __restrict__ spkr,
+                                                        const float* __restrict__ dict, const float* __restrict__ spk_tab,
+                                                        float* __restrict__ x, int U, int E, int C, int n_emb, int n_spk,
+                                                        int* __restrict__ err) {
+    __shared__ float tile[64][65];
+    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 rows of 64
+    // load: rows = time, cols = channel (contiguous reads along the embedding row)
+    for (int r = ty; r < 64; r += 4) {
+        const int t = t0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (t < U && c < C) {
+            if (c < E) {
+                int64_t id = code[(size_t)b * U + t];
+                if (id < 0 || id >= n_emb) { atomicExch(err, 1); id = 0; }
+                v = dict[(size_t)id * E + c];
+            } else {
+                int64_t s = spkr[b];
+                if (s < 0 || s >= n_spk) { atomicExch(err, 2); s = 0; }
+                v = spk_tab[(size_t)s * E + (c - E)];
+            }
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, t = t0 + tx;
+        if (c < C && t < U) x[((size_t)b * C + c) * U + t] = tile[tx][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TTE input: x[b, c, s] = tok_emb[phones[b,s]][c] + pe[S][c]   (parrot.py:94-95, fft.py:17-19, Q1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tte_embed_kernel(const int64_t* __restrict__ phones, const float* __restrict__ emb,
+                                                        const float* __restrict__ pe_row, float* __restrict__ x, int S, int D,
+                                                        int vocab, int* __restrict__ err) {
+    __shared__ float tile[64][65];
+    const int s0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int s = s0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (s < S && c < D) {
+            int64_t id = phones[(size_t)b * S + s];
+            if (id < 0 || id >= vocab) { atomicExch(err, 3); id = 0; }
+            v = pe_row[c] + emb[(size_t)id * D + c];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, s = s0 + tx;
+        if (c < D && s < S) x[((size_t)b * D + c) * S + s] = tile[tx][r];
+    }
+}
+
+// x[b, c, t] += tab[id[b]][c]      (speaker embedding add, parrot.py:98-99, Q6: all positions incl. pads)
+__global__ void add_channel_vec_kernel(float* __restrict__ x, const int64_t* __restrict__ id, const float* __restrict__ tab,
+                                       int C, int T, int n_rows, size_t total, int* __restrict__ err) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / T) % C);
+    const int b = (int)(i / ((size_t)T * C));
+    int64_t s = id[b];
+    if (s < 0 || s >= n_rows) { atomicExch(err, 4); s = 0; }
+    x[i] = x[i] + tab[(size_t)s * C + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over channels of a channel-first tensor (fft.py:91-92,98-99; duration.py:32,36):
+// biased variance, eps inside the sqrt, affine.  Optional ReLU on the input (duration predictor:
+// Conv -> ReLU -> LayerNorm).  One block = 64 consecutive t (one per lane) x 4 waves striding the
+// channels; two passes over L2-resident data (mean, then centred variance) like torch's CPU kernel
+// in exact arithmetic order-insensitivity terms; cross-wave combine through LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y, int C, int T,
+                                                           float eps, int relu_in) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const bool ok = t < T;
+    const float* xb = x + (size_t)b * C * T + t;
+    float s = 0.f;
+    if (ok)
+        for (int c = wave; c < C; c += 4) {
+            float v = xb[(size_t)c * T];
+            if (relu_in) v = v > 0.f ? v : 0.f;
+            s += v;
+        }
+    red[wave][lane] = s;
+    __syncthreads();
+    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    __syncthreads();
+    float q = 0.f;
+    if (ok)
+        for (int c = wave; c < C; c += 4) {
+            float v = xb[(size_t)c * T];
+            if (relu_in) v = v > 0.f ? v : 0.f;
+            const float d = v - mean;
+            q += d * d;
+        }
+    red[wave][lane] = q;
+    __syncthreads();
+    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (ok) {
+        float* yb = y + (size_t)b * C * T + t;
+        for (int c = wave; c < C; c += 4) {
+            float v = xb[(size_t)c * T];
+            if (relu_in) v = v > 0.f ? v : 0.f;
+            yb[(size_t)c * T] = (v - mean) * rstd * gamma[c] + beta[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax of attention scores with a key-padding mask (torch MHA math path, Q3):
+// P[r, :] = softmax(S[r, :] + (-inf where key masked)).  One wave per row, wave-shuffle reductions.
+// rows = B*H*T, row r belongs to batch r / (H*T).  key_valid (B,T) u8 1 = attend.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void softmax_mask_kernel(float* __restrict__ s, const uint8_t* __restrict__ key_valid, int rows,
+                                                           int T, int HT) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / HT;
+    float* sr = s + (size_t)row * T;
+    const uint8_t* kv = key_valid + (size_t)b * T;
+    float mx = -INFINITY;
+    for (int t = lane; t < T; t += 64) {
+        const float v = kv[t] ? sr[t] : -INFINITY;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const float e = kv[t] ? expf(sr[t] - mx) : 0.f;
+        sr[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    for (int t = lane; t < T; t += 64) sr[t] = sr[t] / sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Durations (parrot.py:82-86, duration.py:46-47): ld = masked_fill(ld, pad, 0);
+// dur = max(rint(exp(ld) - 1), 0) as int64 (torch.round = round-half-even = rintf);
+// one block per batch row also produces out_len[b] = sum(dur) and the exclusive prefix sums.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void duration_kernel(const float* __restrict__ ld_raw, const uint8_t* __restrict__ src_valid,
+                                                       float* __restrict__ log_dur, int64_t* __restrict__ dur,
+                                                       int32_t* __restrict__ cum /* (B,S) inclusive */, int32_t* __restrict__ out_len,
+                                                       int S) {
+    __shared__ int32_t part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int per = (S + 255) / 256;
+    const int s_begin = tid * per, s_end = min(S, s_begin + per);
+    int32_t local = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        float v = src_valid[(size_t)b * S + s] ? ld_raw[(size_t)b * S + s] : 0.0f;
+        log_dur[(size_t)b * S + s] = v;
+        float d = rintf(expf(v) - 1.0f);
+        d = d > 0.f ? d : 0.f;
+        const int64_t di = (int64_t)d;
+        dur[(size_t)b * S + s] = di;
+        local += (int32_t)di;
+    }
+    part[tid] = local;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int32_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        out_len[b] = run;
+    }
+    __syncthreads();
+    int32_t run = part[tid];
+    for (int s = s_begin; s < s_end; ++s) {
+        run += (int32_t)dur[(size_t)b * S + s];
+        cum[(size_t)b * S + s] = run;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Length regulator + positional row (duration.py:6-24, parrot.py:106, data.py:8-20):
+// y[b, c, t] = (t < len_b ? enc[b, c, src(t)] : 0) + pe[L][c], src(t) = first s with cum[b,s] > t;
+// tgt_mask[b,t] = t <= len_b (Q2).   grid (ceil(L/256), B).  idx is recomputed per (b,t) once and
+// reused over channels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ enc, const int32_t* __restrict__ cum,
+                                                              const int32_t* __restrict__ out_len, const float* __restrict__ pe_row,
+                                                              float* __restrict__ y, uint8_t* __restrict__ tgt_mask, int S, int L, int D) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const int len = out_len[b];
+    tgt_mask[(size_t)b * L + t] = (t <= len) ? 1 : 0;
+    int src = -1;
+    if (t < len) {
+        const int32_t* cb = cum + (size_t)b * S;
+        int lo = 0, hi = S - 1;  // smallest s with cum[s] > t
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cb[mid] > t) hi = mid; else lo = mid + 1;
+        }
+        src = lo;
+    }
+    const float* eb = enc + (size_t)b * D * S;
+    float* yb = y + (size_t)b * D * L + t;
+    for (int c = 0; c < D; ++c) {
+        const float v = (src >= 0) ? eb[(size_t)c * S + src] : 0.0f;
+        yb[(size_t)c * L] = pe_row[c] + v;
+    }
+}
+
+// argmax over channels of (B, V, L) logits -> ids (B, L); first maximal index wins (torch.argmax).
+// Optionally also writes logits transposed to the reference's (B, L, V) layout for tests.
+__global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const float* lb = logits + (size_t)b * V * L + t;
+    float best = lb[0];
+    int bi = 0;
+    for (int v = 1; v < V; ++v) {
+        const float x = lb[(size_t)v * L];
+        if (x > best) { best = x; bi = v; }
+    }
+    ids[(size_t)b * L + t] = bi;
+}
+
+// (B, C, T) -> (B, T, C) transpose (tests / optional logits export)
+__global__ __launch_bounds__(256) void transpose_cf_to_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T) {
+    __shared__ float tile[64][65];
+    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, t = t0 + tx;
+        tile[r][tx] = (c < C && t < T) ? x[((size_t)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int t = t0 + r, c = c0 + tx;
+        if (t < T && c < C) y[((size_t)b * T + t) * C + c] = tile[tx][r];
+    }
+}
+
+// wav fp32 -> int16 exactly like numpy's `(x * 32768).astype('int16')` for in-range values
+// (C cast: truncation toward zero; utils/vocoder/inference.py:71-73).
+__global__ void wav_to_int16_kernel(const float* __restrict__ w, int16_t* __restrict__ o, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = (int16_t)(int32_t)(w[i] * 32768.0f);
+}
+
+__global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+
+}  // namespace parrot

@@ -1,0 +1,732 @@
+// parrot_hip.hip -- C ABI + host orchestration of the MI355X Parrot-TTS synthesis path.
+// See include/parrot_hip.h for the contract and the reference lines each entry point replaces.
+#include "../../include/parrot_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "attn.h"
+#include "conv_mfma.h"
+#include "kernels_misc.h"
+
+using namespace parrot;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(PARROT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+#define TRY(expr)                \
+    do {                         \
+        int _r = (expr);         \
+        if (_r != PARROT_OK) return _r; \
+    } while (0)
+
+extern "C" int parrot_abi_version(void) { return PARROT_ABI_VERSION; }
+extern "C" const char* parrot_last_error(void) { return g_err.c_str(); }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Arena {
+    char* base;
+    size_t cap, off;
+    bool ok;
+    Arena(void* p, size_t n) : base((char*)p), cap(n), off(0), ok(true) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        size_t bytes = n * sizeof(T);
+        if (base && off + bytes > cap) ok = false;
+        T* r = base ? (T*)(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// optional per-launch timing of the conv kernel (HIP events on the launch stream), aggregated per
+// tile configuration: feeds bench.py's roofline object.  Off by default.
+// ---------------------------------------------------------------------------------------------
+struct ProfRec {
+    hipEvent_t a, b;
+    int cfg;
+    double flops, bytes;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+extern "C" int parrot_prof_begin(void) {
+    for (auto& r : g_prof) g_prof_pool.push_back({r.a, r.b});
+    g_prof.clear();
+    g_prof_on = true;
+    return PARROT_OK;
+}
+// out[cfg*4 + {0,1,2,3}] = {launches, total ms, algorithmic flops, algorithmic bytes}; n_cfg rows.
+extern "C" int parrot_prof_end(double* out, int32_t n_cfg) {
+    g_prof_on = false;
+    if (!out || n_cfg <= 0) return fail(PARROT_E_INVALID, "prof_end: bad output buffer");
+    for (int i = 0; i < n_cfg * 4; ++i) out[i] = 0.0;
+    for (auto& r : g_prof) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        if (r.cfg < n_cfg) {
+            out[r.cfg * 4 + 0] += 1.0;
+            out[r.cfg * 4 + 1] += ms;
+            out[r.cfg * 4 + 2] += r.flops;
+            out[r.cfg * 4 + 3] += r.bytes;
+        }
+    }
+    return PARROT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv plan
+// ---------------------------------------------------------------------------------------------
+struct parrot_conv {
+    parrot_conv_desc d{};
+    int groups = 1;
+    int M = 0, Mg = 0, Cout = 0, Cin = 0;  // Cin per group
+    int kk = 1, dil = 1, pad_left = 0, u = 1;
+    int cfg = 0;
+    int nchunks = 0, n_it = 0;
+    float* wfrag = nullptr;
+    float* bias = nullptr;
+
+    ~parrot_conv() {
+        if (wfrag) (void)hipFree(wfrag);
+        if (bias) (void)hipFree(bias);
+    }
+    int out_len(int Tin) const {
+        if (!d.transposed) return Tin + 2 * d.padding - d.dilation * (d.k - 1);
+        return (Tin - 1) * d.stride - 2 * d.padding + d.k;
+    }
+};
+
+static int choose_cfg(int M, int k) {
+    if (M <= 32) return 2;
+    if (M <= 64) return 1;
+    return (k <= 3) ? 3 : 0;
+}
+
+// Build a plan.  `groups` > 1: torch grouped-conv weight layout (c_out, c_in/groups, k), d.c_in = TOTAL.
+static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, const float* w, const float* bias) {
+    if (!out || !d || !w) return fail(PARROT_E_INVALID, "conv_create: null argument");
+    if (d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->dilation <= 0 || groups <= 0 || d->c_in % groups || d->c_out % groups)
+        return fail(PARROT_E_INVALID, "conv_create: bad dimensions");
+    std::unique_ptr<parrot_conv> c(new parrot_conv());
+    c->d = *d;
+    c->groups = groups;
+    c->Cout = d->c_out;
+    c->Cin = d->c_in / groups;
+    int dmin = 0;
+    if (d->transposed) {
+        if (groups != 1 || d->dilation != 1 || d->stride <= 0) return fail(PARROT_E_UNSUPPORTED, "conv_create: transposed conv needs groups=1, dilation=1");
+        // polyphase gather form: output tau = t*u + r uses taps kappa = r + p - delta*u, input t + delta
+        const int u = d->stride, p = d->padding, k = d->k;
+        int dlo = 1 << 30, dhi = -(1 << 30);
+        for (int r = 0; r < u; ++r)
+            for (int kap = 0; kap < k; ++kap)
+                if ((r + p - kap) % u == 0) {
+                    int dl = (r + p - kap) / u;
+                    dlo = std::min(dlo, dl);
+                    dhi = std::max(dhi, dl);
+                }
+        if (dlo > dhi) return fail(PARROT_E_INVALID, "conv_create: transposed conv has no taps");
+        dmin = dlo;
+        c->u = u;
+        c->kk = dhi - dlo + 1;
+        c->dil = 1;
+        c->pad_left = -dlo;
+        c->M = d->c_out * u;
+    } else {
+        if (d->stride > 1) return fail(PARROT_E_UNSUPPORTED, "conv_create: strided Conv1d is not on the path");
+        c->u = 1;
+        c->kk = d->k;
+        c->dil = d->dilation;
+        c->pad_left = d->padding;
+        c->M = d->c_out;
+    }
+    c->Mg = c->M / groups;
+    if ((c->kk - 1) * c->dil > CONV_HALO) return fail(PARROT_E_UNSUPPORTED, "conv_create: (k-1)*dilation exceeds the LDS halo (64)");
+    c->cfg = (d->tile_cfg >= 0) ? d->tile_cfg : choose_cfg(c->Mg, c->kk);
+    if (c->cfg >= NUM_TILE_CFGS) return fail(PARROT_E_INVALID, "conv_create: tile_cfg out of range");
+    const TileCfg t = tile_cfg(c->cfg);
+    if (groups > 1 && c->Mg % t.bm) return fail(PARROT_E_UNSUPPORTED, "conv_create: rows per group must be a multiple of the tile height");
+    const int CI = t.ci, QN = CI / 8;
+    c->nchunks = (c->Cin + CI - 1) / CI;
+    c->n_it = c->nchunks * c->kk * QN;
+    const int mtiles = (c->M + t.bm - 1) / t.bm * (t.bm / 32);
+    const size_t nfl = ((size_t)mtiles * c->n_it + 1) * 256;  // +1 group: the kernel prefetches one past the end
+    std::vector<float> pk(nfl, 0.f);
+    const int k = d->k, Cing = c->Cin;
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int ch = 0; ch < c->nchunks; ++ch)
+            for (int j = 0; j < c->kk; ++j)
+                for (int q = 0; q < QN; ++q) {
+                    float* g = pk.data() + ((size_t)mt * c->n_it + ((size_t)ch * c->kk + j) * QN + q) * 256;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int m = mt * 32 + (lane & 31);
+                            const int i = ch * CI + 8 * q + 2 * e + (lane >> 5);
+                            float v = 0.f;
+                            if (m < c->M && i < Cing) {
+                                if (d->transposed) {
+                                    const int o = m / c->u, r = m % c->u;
+                                    const int kap = r + d->padding - (j + dmin) * c->u;
+                                    if (kap >= 0 && kap < k) v = w[((size_t)i * d->c_out + o) * k + kap];
+                                } else {
+                                    v = w[((size_t)m * Cing + i) * k + j];
+                                }
+                            }
+                            g[lane * 4 + e] = v;
+                        }
+                }
+    HIP_TRY(hipMalloc((void**)&c->wfrag, nfl * sizeof(float)));
+    HIP_TRY(hipMemcpy(c->wfrag, pk.data(), nfl * sizeof(float), hipMemcpyHostToDevice));
+    if (bias) {
+        HIP_TRY(hipMalloc((void**)&c->bias, (size_t)d->c_out * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->bias, bias, (size_t)d->c_out * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *out = c.release();
+    return PARROT_OK;
+}
+
+// x_bstride / y_bstride / res_bstride in elements; <= 0 means dense.
+static int conv_launch(const parrot_conv* c, const float* x, const float* res, float* y, int B, int Tin, int epi, float div,
+                       long x_bstride, long y_bstride, long res_bstride, hipStream_t s) {
+    if (B <= 0 || Tin <= 0) return fail(PARROT_E_INVALID, "conv_run: empty batch or sequence");
+    const int Tout = c->out_len(Tin);
+    if (Tout <= 0) return fail(PARROT_E_INVALID, "conv_run: sequence shorter than the kernel");
+    ConvParams p{};
+    p.x = x; p.wfrag = c->wfrag; p.bias = c->bias; p.res = res; p.y = y;
+    p.B = B; p.Cin = c->Cin; p.Tin = Tin; p.M = c->M; p.Cout = c->Cout;
+    p.Ncols = (c->u > 1) ? (Tout + c->u - 1) / c->u : Tout;
+    p.Tout = Tout;
+    p.k = c->kk; p.dil = c->dil; p.pad_left = c->pad_left;
+    p.nchunks = c->nchunks; p.n_it = c->n_it;
+    p.pre = c->d.pre_act; p.pre_slope = c->d.pre_slope; p.act = c->d.act;
+    p.epi = epi; p.div = div; p.u = c->u;
+    p.groups = c->groups; p.Mg = c->Mg;
+    p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
+    p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
+    p.res_bstride = res_bstride > 0 ? res_bstride : p.y_bstride;
+    int cfg = c->cfg;
+    if ((cfg == 0 || cfg == 3) && p.Ncols <= 64 && tile_cfg(4).ci == tile_cfg(cfg).ci) cfg = 4;  // same packing, narrower tile
+    const TileCfg t = tile_cfg(cfg);
+    p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
+    ProfRec rec{};
+    if (g_prof_on) {
+        if (g_prof_pool.empty()) {
+            HIP_TRY(hipEventCreate(&rec.a));
+            HIP_TRY(hipEventCreate(&rec.b));
+        } else {
+            rec.a = g_prof_pool.back().first;
+            rec.b = g_prof_pool.back().second;
+            g_prof_pool.pop_back();
+        }
+        // algorithmic work of the layer (real taps only; DESIGN.md "roofline accounting")
+        const double macs = (double)B * c->d.c_out * c->Cin * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
+        const double elems = (double)B * ((double)c->d.c_in * Tin + (double)c->Cout * Tout * (1 + (res ? 1 : 0) + (epi != EPI_STORE ? 1 : 0)));
+        rec.cfg = cfg;
+        rec.flops = 2.0 * macs;
+        rec.bytes = 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k);
+        HIP_TRY(hipEventRecord(rec.a, s));
+    }
+    HIP_TRY(launch_conv(cfg, p, s));
+    if (g_prof_on) {
+        HIP_TRY(hipEventRecord(rec.b, s));
+        g_prof.push_back(rec);
+    }
+    return PARROT_OK;
+}
+
+extern "C" int parrot_conv_create(parrot_conv_t** out, const parrot_conv_desc* d, const float* w_host, const float* bias_host) {
+    return conv_build(out, d, 1, w_host, bias_host);
+}
+extern "C" void parrot_conv_destroy(parrot_conv_t* c) { delete c; }
+extern "C" int parrot_conv_out_len(const parrot_conv_t* c, int32_t T_in) { return c ? c->out_len(T_in) : PARROT_E_INVALID; }
+extern "C" int parrot_conv_num_tile_cfgs(void) { return NUM_TILE_CFGS; }
+extern "C" int parrot_conv_run(parrot_conv_t* c, const float* x, const float* res, float* y, int32_t B, int32_t T_in,
+                               int32_t epilogue, float div, void* stream) {
+    if (!c || !x || !y) return fail(PARROT_E_INVALID, "conv_run: null argument");
+    if (epilogue < 0 || epilogue > 2) return fail(PARROT_E_INVALID, "conv_run: bad epilogue");
+    return conv_launch(c, x, res, y, B, T_in, epilogue, div, 0, 0, 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// self test: MFMA fragment layout
+// ---------------------------------------------------------------------------------------------
+extern "C" int parrot_selftest(void* stream) {
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 64 * 16 * sizeof(float)));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d);
+    std::vector<float> h(64 * 16);
+    hipError_t e = hipMemcpy(h.data(), d, h.size() * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PARROT_E_HIP, hipGetErrorString(e));
+    for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+            const float want = (float)(col + 1) * (float)(1001 * row + 100000);
+            if (h[lane * 16 + r] != want) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "mfma 32x32x2 layout probe: lane %d reg %d got %g want %g", lane, r, h[lane * 16 + r], want);
+                return fail(PARROT_E_UNSUPPORTED, buf);
+            }
+        }
+    return PARROT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vocoder
+// ---------------------------------------------------------------------------------------------
+struct parrot_voc {
+    parrot_voc_cfg cfg{};
+    float* dict = nullptr;
+    float* spkr = nullptr;
+    int* err = nullptr;
+    std::unique_ptr<parrot_conv> conv_pre, conv_post;
+    std::vector<std::unique_ptr<parrot_conv>> ups, rb;
+    int up_total = 1;
+    ~parrot_voc() {
+        if (dict) (void)hipFree(dict);
+        if (spkr) (void)hipFree(spkr);
+        if (err) (void)hipFree(err);
+    }
+    int chan(int stage) const { return cfg.upsample_initial_channel >> (stage + 1); }
+};
+
+static int upload(float** dst, const float* src, size_t n) {
+    HIP_TRY(hipMalloc((void**)dst, n * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return PARROT_OK;
+}
+
+static int make_conv(std::unique_ptr<parrot_conv>& slot, int cin, int cout, int k, int dil, int pad, int transposed, int stride,
+                     int pre, float slope, int act, const float* w, const float* b, int groups = 1) {
+    parrot_conv_desc d{};
+    d.c_in = cin; d.c_out = cout; d.k = k; d.dilation = dil; d.padding = pad; d.transposed = transposed; d.stride = stride;
+    d.pre_act = pre; d.pre_slope = slope; d.act = act; d.tile_cfg = -1;
+    parrot_conv* c = nullptr;
+    TRY(conv_build(&c, &d, groups, w, b));
+    slot.reset(c);
+    return PARROT_OK;
+}
+
+extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w) {
+    if (!out || !cfg || !w) return fail(PARROT_E_INVALID, "voc_create: null argument");
+    if (cfg->n_stages <= 0 || cfg->n_stages > PARROT_MAX_STAGES || cfg->n_kernels <= 0 || cfg->n_kernels > PARROT_MAX_KERNELS ||
+        cfg->n_dil <= 0 || cfg->n_dil > PARROT_MAX_DIL || (cfg->resblock_type != 1 && cfg->resblock_type != 2))
+        return fail(PARROT_E_INVALID, "voc_create: bad config");
+    const int in_dim = cfg->embedding_dim * (cfg->multispkr ? 2 : 1);
+    if (in_dim != cfg->model_in_dim) return fail(PARROT_E_UNSUPPORTED, "voc_create: model_in_dim must equal embedding_dim * (1 + multispkr) (no f0 / extra feature streams)");
+    if ((cfg->upsample_initial_channel >> cfg->n_stages) < 1) return fail(PARROT_E_INVALID, "voc_create: too many stages for upsample_initial_channel");
+    const int per_rb = (cfg->resblock_type == 1 ? 2 : 1) * cfg->n_dil;
+    if (w->n_rb != cfg->n_stages * cfg->n_kernels * per_rb) return fail(PARROT_E_INVALID, "voc_create: wrong number of resblock convs");
+    std::unique_ptr<parrot_voc> v(new parrot_voc());
+    v->cfg = *cfg;
+    TRY(upload(&v->dict, w->dict, (size_t)cfg->num_embeddings * cfg->embedding_dim));
+    if (cfg->multispkr) {
+        if (!w->spkr) return fail(PARROT_E_INVALID, "voc_create: multispkr without spkr table");
+        TRY(upload(&v->spkr, w->spkr, (size_t)cfg->n_spkr * cfg->embedding_dim));
+    }
+    HIP_TRY(hipMalloc((void**)&v->err, sizeof(int)));
+    HIP_TRY(hipMemset(v->err, 0, sizeof(int)));
+    const int C0 = cfg->upsample_initial_channel;
+    TRY(make_conv(v->conv_pre, cfg->model_in_dim, C0, 7, 1, 3, 0, 1, PRE_NONE, 0.f, ACT_NONE, w->conv_pre_w, w->conv_pre_b));
+    v->ups.resize(cfg->n_stages);
+    v->rb.resize(w->n_rb);
+    for (int i = 0; i < cfg->n_stages; ++i) {
+        const int cin = C0 >> i, cout = C0 >> (i + 1), u = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
+        v->up_total *= u;
+        TRY(make_conv(v->ups[i], cin, cout, k, 1, (k - u) / 2, 1, u, PRE_LRELU, 0.1f, ACT_NONE, w->ups_w[i], w->ups_b[i]));
+        for (int j = 0; j < cfg->n_kernels; ++j) {
+            const int rk = cfg->resblock_kernel_sizes[j];
+            for (int m = 0; m < cfg->n_dil; ++m) {
+                const int dl = cfg->resblock_dilation_sizes[j][m];
+                const int base = (i * cfg->n_kernels + j) * per_rb;
+                if (cfg->resblock_type == 1) {
+                    TRY(make_conv(v->rb[base + 2 * m], cout, cout, rk, dl, (rk * dl - dl) / 2, 0, 1, PRE_LRELU, 0.1f, ACT_NONE,
+                                  w->rb_w[base + 2 * m], w->rb_b[base + 2 * m]));
+                    TRY(make_conv(v->rb[base + 2 * m + 1], cout, cout, rk, 1, (rk - 1) / 2, 0, 1, PRE_LRELU, 0.1f, ACT_NONE,
+                                  w->rb_w[base + 2 * m + 1], w->rb_b[base + 2 * m + 1]));
+                } else {
+                    TRY(make_conv(v->rb[base + m], cout, cout, rk, dl, (rk * dl - dl) / 2, 0, 1, PRE_LRELU, 0.1f, ACT_NONE,
+                                  w->rb_w[base + m], w->rb_b[base + m]));
+                }
+            }
+        }
+    }
+    // final F.leaky_relu(x) uses the DEFAULT slope 0.01 (models.py:107, quirk Q5)
+    TRY(make_conv(v->conv_post, C0 >> cfg->n_stages, 1, 7, 1, 3, 0, 1, PRE_LRELU, 0.01f, ACT_TANH, w->conv_post_w, w->conv_post_b));
+    *out = v.release();
+    return PARROT_OK;
+}
+extern "C" void parrot_voc_destroy(parrot_voc_t* v) { delete v; }
+
+static size_t voc_max_act(const parrot_voc* v, int B, int U) {
+    size_t mx = (size_t)B * v->cfg.upsample_initial_channel * U;
+    size_t T = U;
+    for (int i = 0; i < v->cfg.n_stages; ++i) {
+        T *= v->cfg.upsample_rates[i];
+        mx = std::max(mx, (size_t)B * v->chan(i) * T);
+    }
+    return mx;
+}
+
+extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t U) {
+    if (!v || B <= 0 || U <= 0) return 0;
+    Arena a(nullptr, 0);
+    a.take<float>((size_t)B * v->cfg.model_in_dim * U);
+    const size_t mx = voc_max_act(v, B, U);
+    for (int i = 0; i < 5; ++i) a.take<float>(mx);
+    return align_up(a.off, 256);
+}
+
+extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, int32_t B, int32_t U, float* wav_out,
+                                  float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!v || !code || !wav_out || !ws) return fail(PARROT_E_INVALID, "voc_forward: null argument");
+    if (B <= 0 || U <= 0) return fail(PARROT_E_INVALID, "voc_forward: empty batch");
+    if (v->cfg.multispkr && !spkr) return fail(PARROT_E_INVALID, "voc_forward: multispkr model needs spkr ids");
+    hipStream_t s = (hipStream_t)stream;
+    const parrot_voc_cfg& c = v->cfg;
+    Arena a(ws, ws_bytes);
+    float* x0 = a.take<float>((size_t)B * c.model_in_dim * U);
+    const size_t mx = voc_max_act(v, B, U);
+    float* P[5];
+    for (int i = 0; i < 5; ++i) P[i] = a.take<float>(mx);
+    if (!a.ok) return fail(PARROT_E_NOMEM, "voc_forward: workspace too small");
+
+    {
+        dim3 grid((U + 63) / 64, (c.model_in_dim + 63) / 64, B);
+        hipLaunchKernelGGL(voc_embed_kernel, grid, dim3(256), 0, s, code, spkr, v->dict, v->spkr, x0, U, c.embedding_dim,
+                           c.model_in_dim, c.num_embeddings, c.n_spkr, v->err);
+        HIP_TRY(hipGetLastError());
+    }
+    auto snap = [&](int idx, const float* src, size_t n) -> int {
+        if (stage_out && stage_out[idx]) HIP_TRY(hipMemcpyAsync(stage_out[idx], src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return PARROT_OK;
+    };
+    int ia = 0;
+    TRY(conv_launch(v->conv_pre.get(), x0, nullptr, P[ia], B, U, EPI_STORE, 1.f, 0, 0, 0, s));
+    TRY(snap(0, P[ia], (size_t)B * c.upsample_initial_channel * U));
+    int T = U;
+    const int nk = c.n_kernels, nd = c.n_dil;
+    const int per_rb = (c.resblock_type == 1 ? 2 : 1) * nd;
+    for (int i = 0; i < c.n_stages; ++i) {
+        float* A = P[ia];
+        float* X = P[(ia + 1) % 5];
+        float* XS = P[(ia + 2) % 5];
+        float* T1 = P[(ia + 3) % 5];
+        float* RA = P[(ia + 4) % 5];
+        float* RB = A;  // the stage input is dead once ups[i] has consumed it
+        TRY(conv_launch(v->ups[i].get(), A, nullptr, X, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+        T = v->ups[i]->out_len(T);
+        const size_t n_act = (size_t)B * v->chan(i) * T;
+        TRY(snap(1 + 2 * i, X, n_act));
+        for (int j = 0; j < nk; ++j) {
+            const float* r = X;
+            const int base = (i * nk + j) * per_rb;
+            const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
+            for (int m = 0; m < nd; ++m) {
+                const bool last = (m == nd - 1);
+                float* dst = last ? XS : ((m & 1) ? RB : RA);
+                if (c.resblock_type == 1) {
+                    TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+                    TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, s));
+                } else {
+                    TRY(conv_launch(v->rb[base + m].get(), r, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, s));
+                }
+                r = dst;
+            }
+        }
+        TRY(snap(2 + 2 * i, XS, n_act));
+        ia = (ia + 2) % 5;
+    }
+    TRY(conv_launch(v->conv_post.get(), P[ia], nullptr, wav_out, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+    return PARROT_OK;
+}
+
+extern "C" int parrot_wav_to_int16(const float* wav, int16_t* out, size_t n, void* stream) {
+    if (!wav || !out) return fail(PARROT_E_INVALID, "wav_to_int16: null argument");
+    if (n == 0) return PARROT_OK;
+    hipLaunchKernelGGL(wav_to_int16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wav, out, n);
+    HIP_TRY(hipGetLastError());
+    return PARROT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TTE
+// ---------------------------------------------------------------------------------------------
+struct FftLayer {
+    std::unique_ptr<parrot_conv> qkv, in_proj, out_proj, wo, conv1, conv2;
+    float *an_w = nullptr, *an_b = nullptr, *cn_w = nullptr, *cn_b = nullptr;
+    int heads = 1;
+    ~FftLayer() {
+        for (float* p : {an_w, an_b, cn_w, cn_b})
+            if (p) (void)hipFree(p);
+    }
+};
+
+struct parrot_tte {
+    parrot_tte_cfg cfg{};
+    float *pe = nullptr, *tok = nullptr, *spk = nullptr;
+    float *ln0_w = nullptr, *ln0_b = nullptr, *ln1_w = nullptr, *ln1_b = nullptr;
+    int* err = nullptr;
+    std::unique_ptr<parrot_conv> dp0, dp1, dp_proj, head;
+    std::vector<std::unique_ptr<FftLayer>> enc, dec;
+    ~parrot_tte() {
+        for (float* p : {pe, tok, spk, ln0_w, ln0_b, ln1_w, ln1_b})
+            if (p) (void)hipFree(p);
+        if (err) (void)hipFree(err);
+    }
+};
+
+static int build_fft(std::unique_ptr<FftLayer>& slot, const parrot_tte_cfg& c, int heads, const parrot_fft_weights& w) {
+    std::unique_ptr<FftLayer> L(new FftLayer());
+    const int D = c.d_model, F = c.n_filter_ffn;
+    if (D % heads) return fail(PARROT_E_INVALID, "tte_create: d_model % n_head != 0");  // fft.py:44
+    L->heads = heads;
+    TRY(make_conv(L->qkv, D, 3 * D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.qkv, nullptr));
+    // MHA in_proj: three bias-free (D,D) projections of three different inputs = a grouped 1x1 conv
+    TRY(make_conv(L->in_proj, 3 * D, 3 * D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.in_proj, nullptr, 3));
+    TRY(make_conv(L->out_proj, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.out_proj, nullptr));
+    TRY(make_conv(L->wo, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.wo, nullptr));
+    TRY(make_conv(L->conv1, D, F, c.ffn_k1, 1, (c.ffn_k1 - 1) / 2, 0, 1, PRE_NONE, 0.f, ACT_RELU, w.conv1_w, w.conv1_b));
+    TRY(make_conv(L->conv2, F, D, c.ffn_k2, 1, (c.ffn_k2 - 1) / 2, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.conv2_w, w.conv2_b));
+    TRY(upload(&L->an_w, w.attn_norm_w, D));
+    TRY(upload(&L->an_b, w.attn_norm_b, D));
+    TRY(upload(&L->cn_w, w.conv_norm_w, D));
+    TRY(upload(&L->cn_b, w.conv_norm_b, D));
+    slot = std::move(L);
+    return PARROT_OK;
+}
+
+extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w) {
+    if (!out || !cfg || !w) return fail(PARROT_E_INVALID, "tte_create: null argument");
+    const parrot_tte_cfg& c = *cfg;
+    if (c.d_model <= 0 || c.n_filter_ffn <= 0 || c.max_len <= 0 || c.vocab <= 0 || c.n_codes <= 0 || c.dp_filter <= 0 ||
+        c.enc_layers < 0 || c.dec_layers < 0 || c.ffn_k1 <= 0 || c.ffn_k2 <= 0 || c.dp_kernel <= 0)
+        return fail(PARROT_E_INVALID, "tte_create: bad config");
+    if (!(c.ffn_k1 & 1) || !(c.ffn_k2 & 1)) return fail(PARROT_E_UNSUPPORTED, "tte_create: even FFN kernel sizes change the sequence length");
+    if (c.dp_kernel != 3) return fail(PARROT_E_UNSUPPORTED, "tte_create: duration_predictor.kernel_size != 3 changes the sequence length in the reference (padding=1 is hard-coded, duration.py:34)");
+    std::unique_ptr<parrot_tte> t(new parrot_tte());
+    t->cfg = c;
+    const int D = c.d_model;
+    TRY(upload(&t->pe, w->pe, (size_t)c.max_len * D));
+    TRY(upload(&t->tok, w->tok_emb, (size_t)c.vocab * D));
+    if (c.n_speaker > 1) {
+        if (!w->speaker_emb) return fail(PARROT_E_INVALID, "tte_create: n_speaker > 1 without speaker_emb");
+        TRY(upload(&t->spk, w->speaker_emb, (size_t)c.n_speaker * D));
+    }
+    HIP_TRY(hipMalloc((void**)&t->err, sizeof(int)));
+    HIP_TRY(hipMemset(t->err, 0, sizeof(int)));
+    TRY(make_conv(t->dp0, D, c.dp_filter, c.dp_kernel, 1, (c.dp_kernel - 1) / 2, 0, 1, PRE_NONE, 0.f, ACT_NONE, w->dp_conv0_w, w->dp_conv0_b));
+    TRY(make_conv(t->dp1, c.dp_filter, c.dp_filter, c.dp_kernel, 1, 1 /* Q4 */, 0, 1, PRE_NONE, 0.f, ACT_NONE, w->dp_conv1_w, w->dp_conv1_b));
+    TRY(make_conv(t->dp_proj, c.dp_filter, 1, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w->dp_proj_w, w->dp_proj_b));
+    TRY(upload(&t->ln0_w, w->dp_ln0_w, c.dp_filter));
+    TRY(upload(&t->ln0_b, w->dp_ln0_b, c.dp_filter));
+    TRY(upload(&t->ln1_w, w->dp_ln1_w, c.dp_filter));
+    TRY(upload(&t->ln1_b, w->dp_ln1_b, c.dp_filter));
+    t->enc.resize(c.enc_layers);
+    t->dec.resize(c.dec_layers);
+    for (int i = 0; i < c.enc_layers; ++i) TRY(build_fft(t->enc[i], c, c.enc_heads, w->enc[i]));
+    for (int i = 0; i < c.dec_layers; ++i) TRY(build_fft(t->dec[i], c, c.dec_heads, w->dec[i]));
+    TRY(make_conv(t->head, D, c.n_codes, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w->head_w, w->head_b));
+    *out = t.release();
+    return PARROT_OK;
+}
+extern "C" void parrot_tte_destroy(parrot_tte_t* t) { delete t; }
+
+struct TteState {  // persists between encode and decode (sized by B,S only)
+    float* enc_out;
+    int32_t* cum;
+    int32_t* out_len;
+};
+static TteState tte_state(const parrot_tte* t, Arena& a, int B, int S) {
+    TteState st;
+    st.enc_out = a.take<float>((size_t)B * t->cfg.d_model * S);
+    st.cum = a.take<int32_t>((size_t)B * S);
+    st.out_len = a.take<int32_t>((size_t)B);
+    return st;
+}
+struct TteScratch {
+    float *x, *n, *qkv1, *qkv2, *scores, *ctx, *o, *h, *f, *logits;
+};
+static TteScratch tte_scratch(const parrot_tte* t, Arena& a, int B, int T, bool with_logits) {
+    const parrot_tte_cfg& c = t->cfg;
+    const int Hmax = std::max(std::max(c.enc_heads, c.dec_heads), 1);
+    const size_t DT = (size_t)B * c.d_model * T;
+    const int Fmax = std::max(c.n_filter_ffn, c.dp_filter);
+    TteScratch s;
+    s.x = a.take<float>(DT);
+    s.n = a.take<float>(std::max(DT, (size_t)B * c.dp_filter * T));
+    s.qkv1 = a.take<float>(3 * DT);
+    s.qkv2 = a.take<float>(3 * DT);
+    s.scores = a.take<float>((size_t)B * Hmax * T * T);
+    s.ctx = a.take<float>(DT);
+    s.o = a.take<float>(DT);
+    s.h = a.take<float>(DT);
+    s.f = a.take<float>((size_t)B * Fmax * T);
+    s.logits = with_logits ? a.take<float>((size_t)B * c.n_codes * T) : nullptr;
+    return s;
+}
+
+extern "C" size_t parrot_tte_state_bytes(const parrot_tte_t* t, int32_t B, int32_t S) {
+    if (!t || B <= 0 || S <= 0) return 0;
+    Arena a(nullptr, 0);
+    (void)tte_state(t, a, B, S);
+    return align_up(a.off, 256);
+}
+extern "C" size_t parrot_tte_workspace_bytes(const parrot_tte_t* t, int32_t B, int32_t S, int32_t L_max) {
+    if (!t || B <= 0 || S <= 0) return 0;
+    Arena a(nullptr, 0);
+    (void)tte_scratch(t, a, B, std::max(S, L_max), L_max > 0);
+    return align_up(a.off, 256);
+}
+
+static int layernorm(const float* x, const float* g, const float* b, float* y, int B, int C, int T, int relu_in, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_cf_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, g, b, y, C, T, 1e-5f, relu_in);
+    HIP_TRY(hipGetLastError());
+    return PARROT_OK;
+}
+
+// FFTBlock.forward (fft.py:94-100): x -> out (may alias x).  valid (B,T) u8: 1 = attend to this key.
+static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, float* x, const uint8_t* valid, int B, int T, hipStream_t s) {
+    const int D = t->cfg.d_model, H = L->heads, hd = D / H;
+    TRY(layernorm(x, L->an_w, L->an_b, w.n, B, D, T, 0, s));
+    TRY(conv_launch(L->qkv.get(), w.n, nullptr, w.qkv1, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+    TRY(conv_launch(L->in_proj.get(), w.qkv1, nullptr, w.qkv2, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+    const long DT = (long)D * T;
+    {   // scores[b,h][tq][tk] = sum_c (q[c][tq] * sqrt(1/hd)) * k[c][tk]
+        BgemmParams p{};
+        p.A = w.qkv2; p.B = w.qkv2 + DT; p.C = w.scores;
+        p.M = T; p.N = T; p.K = hd;
+        p.a_sk = T; p.a_sm = 1; p.b_sk = T; p.b_sn = 1;
+        p.a_zb = 3 * DT; p.a_zh = (long)hd * T; p.b_zb = 3 * DT; p.b_zh = (long)hd * T;
+        p.c_zb = (long)H * T * T; p.c_zh = (long)T * T; p.ldc = T; p.H = H;
+        p.alpha = (float)std::sqrt(1.0 / (double)hd);
+        hipLaunchKernelGGL(bgemm_mfma_kernel, dim3((T + 63) / 64, (T + 63) / 64, B * H), dim3(256), 0, s, p);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(softmax_mask_kernel, dim3((B * H * T + 3) / 4), dim3(256), 0, s, w.scores, valid, B * H * T, T, H * T);
+    HIP_TRY(hipGetLastError());
+    {   // ctx[b][h*hd + c][tq] = sum_tk v[c][tk] * P[tq][tk]
+        BgemmParams p{};
+        p.A = w.qkv2 + 2 * DT; p.B = w.scores; p.C = w.ctx;
+        p.M = hd; p.N = T; p.K = T;
+        p.a_sk = 1; p.a_sm = T; p.b_sk = 1; p.b_sn = T;
+        p.a_zb = 3 * DT; p.a_zh = (long)hd * T; p.b_zb = (long)H * T * T; p.b_zh = (long)T * T;
+        p.c_zb = DT; p.c_zh = (long)hd * T; p.ldc = T; p.H = H;
+        p.alpha = 1.0f;
+        hipLaunchKernelGGL(bgemm_mfma_kernel, dim3((T + 63) / 64, (hd + 63) / 64, B * H), dim3(256), 0, s, p);
+        HIP_TRY(hipGetLastError());
+    }
+    TRY(conv_launch(L->out_proj.get(), w.ctx, nullptr, w.o, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+    TRY(conv_launch(L->wo.get(), w.o, x, w.h, B, T, EPI_STORE, 1.f, 0, 0, 0, s));          // h = x + attn
+    TRY(layernorm(w.h, L->cn_w, L->cn_b, w.n, B, D, T, 0, s));
+    TRY(conv_launch(L->conv1.get(), w.n, nullptr, w.f, B, T, EPI_STORE, 1.f, 0, 0, 0, s));  // relu fused
+    TRY(conv_launch(L->conv2.get(), w.f, w.h, x, B, T, EPI_STORE, 1.f, 0, 0, 0, s));        // out = h + ffn
+    return PARROT_OK;
+}
+
+extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, int32_t B,
+                                 int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens, void* state, size_t state_bytes, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (!t || !phones || !src_mask || !log_dur || !dur || !out_lens || !state || !ws) return fail(PARROT_E_INVALID, "tte_encode: null argument");
+    if (B <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_encode: empty batch");
+    const parrot_tte_cfg& c = t->cfg;
+    if (S >= c.max_len) return fail(PARROT_E_RANGE, "tte_encode: sequence length >= max_len (pe[T] out of range, fft.py:18)");
+    if (t->spk && !speaker) return fail(PARROT_E_INVALID, "tte_encode: multi-speaker model needs speaker ids");
+    hipStream_t s = (hipStream_t)stream;
+    Arena sa(state, state_bytes);
+    TteState st = tte_state(t, sa, B, S);
+    Arena a(ws, ws_bytes);
+    TteScratch w = tte_scratch(t, a, B, S, false);
+    if (!sa.ok || !a.ok) return fail(PARROT_E_NOMEM, "tte_encode: state/workspace too small");
+    const int D = c.d_model;
+    hipLaunchKernelGGL(tte_embed_kernel, dim3((S + 63) / 64, (D + 63) / 64, B), dim3(256), 0, s, phones, t->tok, t->pe + (size_t)S * D,
+                       w.x, S, D, c.vocab, t->err);
+    HIP_TRY(hipGetLastError());
+    for (auto& L : t->enc) TRY(fft_block(t, L.get(), w, w.x, src_mask, B, S, s));
+    if (t->spk) {
+        const size_t total = (size_t)B * D * S;
+        hipLaunchKernelGGL(add_channel_vec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w.x, speaker, t->spk, D, S,
+                           c.n_speaker, total, t->err);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(st.enc_out, w.x, (size_t)B * D * S * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // duration predictor (duration.py:29-48): conv -> relu -> LN -> conv(pad 1) -> relu -> LN -> linear
+    const int NF = c.dp_filter;
+    TRY(conv_launch(t->dp0.get(), w.x, nullptr, w.f, B, S, EPI_STORE, 1.f, 0, 0, 0, s));
+    TRY(layernorm(w.f, t->ln0_w, t->ln0_b, w.n, B, NF, S, 1, s));
+    TRY(conv_launch(t->dp1.get(), w.n, nullptr, w.f, B, S, EPI_STORE, 1.f, 0, 0, 0, s));
+    TRY(layernorm(w.f, t->ln1_w, t->ln1_b, w.n, B, NF, S, 1, s));
+    TRY(conv_launch(t->dp_proj.get(), w.n, nullptr, w.o, B, S, EPI_STORE, 1.f, 0, 0, 0, s));  // (B,1,S)
+    hipLaunchKernelGGL(duration_kernel, dim3(B), dim3(256), 0, s, w.o, src_mask, log_dur, dur, st.cum, st.out_len, S);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_lens, st.out_len, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    return PARROT_OK;
+}
+
+extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int64_t* ids, uint8_t* tgt_mask, float* logits,
+                                 void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+    if (!t || !ids || !tgt_mask || !state || !ws) return fail(PARROT_E_INVALID, "tte_decode: null argument");
+    if (B <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_decode: empty batch");
+    if (L <= 0) return fail(PARROT_E_INVALID, "tte_decode: L must be > 0 (all durations zero: the reference fails in MultiheadAttention too)");
+    const parrot_tte_cfg& c = t->cfg;
+    if (L >= c.max_len) return fail(PARROT_E_RANGE, "tte_decode: expanded length >= max_len (pe[T] out of range, fft.py:18)");
+    hipStream_t s = (hipStream_t)stream;
+    Arena sa(state, state_bytes);
+    TteState st = tte_state(t, sa, B, S);
+    Arena a(ws, ws_bytes);
+    TteScratch w = tte_scratch(t, a, B, std::max(S, L), true);
+    if (!sa.ok || !a.ok) return fail(PARROT_E_NOMEM, "tte_decode: state/workspace too small");
+    const int D = c.d_model, V = c.n_codes;
+    hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, st.enc_out, st.cum, st.out_len,
+                       t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D);
+    HIP_TRY(hipGetLastError());
+    for (auto& Ly : t->dec) TRY(fft_block(t, Ly.get(), w, w.x, tgt_mask, B, L, s));
+    TRY(conv_launch(t->head.get(), w.x, nullptr, w.logits, B, L, EPI_STORE, 1.f, 0, 0, 0, s));
+    hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, w.logits, ids, V, L);
+    HIP_TRY(hipGetLastError());
+    if (logits) {
+        hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((L + 63) / 64, (V + 63) / 64, B), dim3(256), 0, s, w.logits, logits, V, L);
+        HIP_TRY(hipGetLastError());
+    }
+    return PARROT_OK;
+}
+
+// device-side input-range flag (bad unit / speaker / phone ids <-> the reference's Embedding IndexError).
+// Synchronises the stream; returns 0 or PARROT_E_RANGE and clears the flag.
+static int read_flag(int* err, hipStream_t s, const char* who) {
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h) {
+        HIP_TRY(hipMemsetAsync(err, 0, sizeof(int), s));
+        return fail(PARROT_E_RANGE, std::string(who) + ": embedding index out of range (code " + std::to_string(h) + ")");
+    }
+    return PARROT_OK;
+}
+extern "C" int parrot_voc_check(parrot_voc_t* v, void* stream) { return v ? read_flag(v->err, (hipStream_t)stream, "vocoder") : PARROT_E_INVALID; }
+extern "C" int parrot_tte_check(parrot_tte_t* t, void* stream) { return t ? read_flag(t->err, (hipStream_t)stream, "tte") : PARROT_E_INVALID; }

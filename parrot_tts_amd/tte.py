@@ -1,0 +1,223 @@
+"""Drop-in ``Parrot`` for reference modules/parrot.py:12-120 backed by libparrot_hip.so.
+
+Same constructor ``Parrot(data_config, src_vocab_size, src_pad_idx)`` (reads
+``<root_path>/speakers.json`` like the reference, parrot.py:24-26), same ``state_dict`` keys
+(SURVEY 8b), same ``infer(batch) -> List[List[int]]`` / ``forward(batch, inference=True)``.
+The module only holds parameters; the arithmetic runs in the HIP library.  Training forward
+(``inference=False``) is out of scope and raises."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import dptr, require_cuda, stream_ptr
+from .synth import sinusoid_table
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = False) -> None:
+    """Register ``tensor`` under a dotted state_dict key, creating plain container modules on the way
+    (numeric path parts are fine: nn.Module accepts '0' as a child name, as ModuleList does)."""
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, nn.Module())
+        m = m._modules[p]
+    if buffer:
+        m.register_buffer(parts[-1], tensor)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def parrot_param_shapes(cfg: dict, vocab: int, n_speaker: int) -> Dict[str, tuple]:
+    """state_dict key -> shape for the reference ``Parrot`` ([verified] there)."""
+    tr, dp = cfg["transformer"], cfg["duration_predictor"]
+    D, F = tr["d_model"], tr["conv_n_filter"]
+    k1, k2 = tr["conv_kernel_sizes"]
+    NF, DK = dp["n_filter"], dp["kernel_size"]
+    sh = {"tok_emb.weight": (vocab, D)}
+    if n_speaker > 1:
+        sh["speaker_emb.weight"] = (n_speaker, D)
+    sh["duration_predictor.layers.0.conv.weight"] = (NF, D, DK)
+    sh["duration_predictor.layers.0.conv.bias"] = (NF,)
+    sh["duration_predictor.layers.4.conv.weight"] = (NF, NF, DK)
+    sh["duration_predictor.layers.4.conv.bias"] = (NF,)
+    for i in (2, 6):
+        sh[f"duration_predictor.layers.{i}.weight"] = (NF,)
+        sh[f"duration_predictor.layers.{i}.bias"] = (NF,)
+    sh["duration_predictor.proj.weight"] = (1, NF)
+    sh["duration_predictor.proj.bias"] = (1,)
+    for side in ("encoder", "decoder"):
+        for n in range(tr[side]["n_layer"]):
+            p = f"{side}_layers.{n}."
+            sh[p + "attention.qkv.weight"] = (3 * D, D)
+            sh[p + "attention.mha.in_proj_weight"] = (3 * D, D)
+            sh[p + "attention.mha.out_proj.weight"] = (D, D)
+            sh[p + "attention.wo.weight"] = (D, D)
+            sh[p + "convlayer.conv1.weight"] = (F, D, k1)
+            sh[p + "convlayer.conv1.bias"] = (F,)
+            sh[p + "convlayer.conv2.weight"] = (D, F, k2)
+            sh[p + "convlayer.conv2.bias"] = (D,)
+            for nm in ("attn_norm", "conv_norm"):
+                sh[p + nm + ".weight"] = (D,)
+                sh[p + nm + ".bias"] = (D,)
+    sh["head.weight"] = (cfg["preprocess"]["hubert_codes"], D)
+    sh["head.bias"] = (cfg["preprocess"]["hubert_codes"],)
+    return sh
+
+
+class Parrot(nn.Module):
+    def __init__(self, data_config, src_vocab_size, src_pad_idx):
+        super().__init__()
+        tr = data_config["transformer"]
+        self.max_len, self.d_model = tr["max_len"], tr["d_model"]
+        self.data_config = data_config
+        self.src_vocab_size, self.src_pad_idx = int(src_vocab_size), src_pad_idx
+        if self.d_model % tr["encoder"]["n_head"] or self.d_model % tr["decoder"]["n_head"]:
+            raise AssertionError("d_model % n_head != 0")  # reference modules/fft.py:44
+        spk_path = os.path.join(data_config["path"]["root_path"], "speakers.json")
+        with open(spk_path, "r") as f:
+            self.n_speaker = len(json.load(f))
+        _attach(self, "pos_emb.pe", sinusoid_table(self.max_len, self.d_model), buffer=True)
+        gen = torch.Generator().manual_seed(0)
+        for key, shape in parrot_param_shapes(data_config, self.src_vocab_size, self.n_speaker).items():
+            if key.endswith("norm.weight") or key in ("duration_predictor.layers.2.weight", "duration_predictor.layers.6.weight"):
+                t = torch.ones(shape)
+            elif key.endswith("bias"):
+                t = torch.zeros(shape)
+            else:
+                fan_in = 1
+                for s in shape[1:]:
+                    fan_in *= s
+                t = torch.randn(shape, generator=gen) / max(fan_in, 1) ** 0.5
+            _attach(self, key, t)
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_device = None
+
+    # ---- parameter bookkeeping ----------------------------------------------------------------
+    def _invalidate(self):
+        if self._handle is not None:
+            _lib.lib().parrot_tte_destroy(self._handle)
+        self._handle = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        self._invalidate()
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    def _apply(self, fn, recurse=True):
+        self._invalidate()
+        return super()._apply(fn, recurse)
+
+    def __del__(self):
+        try:
+            self._invalidate()
+        except Exception:
+            pass
+
+    # ---- HIP handle ---------------------------------------------------------------------------
+    def _build(self, device):
+        cfgd = self.data_config
+        tr, dp = cfgd["transformer"], cfgd["duration_predictor"]
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
+        P = lambda k: _lib.fptr(sd[k])  # noqa: E731
+        cfg = _lib.TteCfg(tr["d_model"], tr["conv_n_filter"], tr["conv_kernel_sizes"][0], tr["conv_kernel_sizes"][1], tr["max_len"],
+                          tr["encoder"]["n_layer"], tr["encoder"]["n_head"], tr["decoder"]["n_layer"], tr["decoder"]["n_head"],
+                          dp["n_filter"], dp["kernel_size"], self.src_vocab_size, self.n_speaker, cfgd["preprocess"]["hubert_codes"])
+
+        def fft(prefix):
+            return _lib.FftWeights(P(prefix + "attention.qkv.weight"), P(prefix + "attention.mha.in_proj_weight"),
+                                   P(prefix + "attention.mha.out_proj.weight"), P(prefix + "attention.wo.weight"),
+                                   P(prefix + "convlayer.conv1.weight"), P(prefix + "convlayer.conv1.bias"),
+                                   P(prefix + "convlayer.conv2.weight"), P(prefix + "convlayer.conv2.bias"),
+                                   P(prefix + "attn_norm.weight"), P(prefix + "attn_norm.bias"),
+                                   P(prefix + "conv_norm.weight"), P(prefix + "conv_norm.bias"))
+
+        enc = (_lib.FftWeights * max(1, cfg.enc_layers))(*[fft(f"encoder_layers.{n}.") for n in range(cfg.enc_layers)])
+        dec = (_lib.FftWeights * max(1, cfg.dec_layers))(*[fft(f"decoder_layers.{n}.") for n in range(cfg.dec_layers)])
+        w = _lib.TteWeights()
+        w.pe, w.tok_emb = P("pos_emb.pe"), P("tok_emb.weight")
+        w.speaker_emb = P("speaker_emb.weight") if self.n_speaker > 1 else None
+        d = "duration_predictor."
+        w.dp_conv0_w, w.dp_conv0_b = P(d + "layers.0.conv.weight"), P(d + "layers.0.conv.bias")
+        w.dp_ln0_w, w.dp_ln0_b = P(d + "layers.2.weight"), P(d + "layers.2.bias")
+        w.dp_conv1_w, w.dp_conv1_b = P(d + "layers.4.conv.weight"), P(d + "layers.4.conv.bias")
+        w.dp_ln1_w, w.dp_ln1_b = P(d + "layers.6.weight"), P(d + "layers.6.bias")
+        w.dp_proj_w, w.dp_proj_b = P(d + "proj.weight"), P(d + "proj.bias")
+        w.enc, w.dec = C.cast(enc, C.POINTER(_lib.FftWeights)), C.cast(dec, C.POINTER(_lib.FftWeights))
+        w.head_w, w.head_b = P("head.weight"), P("head.bias")
+        hdl = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().parrot_tte_create(C.byref(hdl), C.byref(cfg), C.byref(w)))
+        self._handle, self._handle_device = hdl, device
+
+    # ---- forward ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _run(self, batch, want_logits: bool):
+        phones = batch["phones"]
+        require_cuda(phones, "batch['phones']")
+        dev = phones.device
+        if self._handle is None or self._handle_device != dev:
+            self._invalidate()
+            self._build(dev)
+        lib = _lib.lib()
+        phones = phones.to(torch.int64).contiguous()
+        B, S = phones.shape
+        src_mask = batch["src_mask"].to(dev)
+        valid = src_mask.to(torch.uint8).contiguous()
+        speaker = None
+        if self.n_speaker > 1:
+            speaker = batch["speaker"].to(dev, torch.int64).contiguous()
+        log_dur = torch.empty((B, S), dtype=torch.float32, device=dev)
+        dur = torch.empty((B, S), dtype=torch.int64, device=dev)
+        lens = torch.empty((B,), dtype=torch.int32, device=dev)
+        state = torch.empty(lib.parrot_tte_state_bytes(self._handle, B, S), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, B, S, 0), dtype=torch.uint8, device=dev)
+        st = stream_ptr(dev)
+        with torch.cuda.device(dev):
+            try:
+                _lib.check(lib.parrot_tte_encode(self._handle, dptr(phones), dptr(valid), dptr(speaker), B, S, dptr(log_dur), dptr(dur),
+                                                 dptr(lens), dptr(state), state.numel(), dptr(ws), ws.numel(), st))
+                lens_h = lens.cpu()  # the one host sync the reference also has (duration.py:10)
+                _lib.check(lib.parrot_tte_check(self._handle, st))
+                L = int(lens_h.max())
+                del ws
+                ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, B, S, L), dtype=torch.uint8, device=dev)
+                ids = torch.empty((B, L), dtype=torch.int64, device=dev)
+                tgt = torch.empty((B, L), dtype=torch.uint8, device=dev)
+                logits = torch.empty((B, L, lib_n_codes(self)), dtype=torch.float32, device=dev) if want_logits else None
+                _lib.check(lib.parrot_tte_decode(self._handle, B, S, L, dptr(ids), dptr(tgt), dptr(logits), dptr(state), state.numel(),
+                                                 dptr(ws), ws.numel(), st))
+            except _lib.ParrotHipError as e:
+                if e.code == -2:  # PARROT_E_RANGE <-> the reference's IndexError (pe[T], Embedding)
+                    raise IndexError(str(e)) from None
+                raise
+        return {"ids": ids, "tgt_mask": tgt.bool(), "log_dur": log_dur, "dur": dur, "lens": lens_h, "logits": logits,
+                "src_mask": src_mask}
+
+    def forward(self, batch, inference=False):
+        if inference is not True:
+            raise NotImplementedError("parrot_tts_amd.Parrot implements the inference path only (training is out of scope)")
+        r = self._run(batch, want_logits=True)
+        return (r["logits"], batch["src_mask"], r["tgt_mask"], r["log_dur"])
+
+    def infer(self, batch) -> List[List[int]]:
+        assert self.training == False  # noqa: E712  (reference modules/parrot.py:113)
+        r = self._run(batch, want_logits=False)
+        ids, msk = r["ids"].cpu(), r["tgt_mask"].cpu()
+        return [c[m].numpy().tolist() for c, m in zip(ids, msk)]
+
+    def infer_dense(self, batch) -> dict:
+        """Batched, device-resident result (ids (B,L), tgt_mask, lens) for pipelines that feed the vocoder
+        directly instead of going through Python lists."""
+        assert self.training == False  # noqa: E712
+        return self._run(batch, want_logits=False)
+
+
+def lib_n_codes(m: "Parrot") -> int:
+    return int(m.data_config["preprocess"]["hubert_codes"])

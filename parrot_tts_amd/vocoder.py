@@ -1,0 +1,297 @@
+"""Drop-in ``CodeGenerator`` for reference utils/vocoder/models.py:122-169 backed by libparrot_hip.so.
+
+Same constructor (``CodeGenerator(h)`` with the AttrDict / dict of utils/vocoder/config.json), same
+``state_dict`` keys (weight-norm ``weight_g``/``weight_v`` as training checkpoints carry them, or
+plain ``weight`` after ``remove_weight_norm()``), same call ``generator(code=LongTensor(B,U),
+spkr=LongTensor(B,1)) -> FloatTensor(B,1,U*prod(upsample_rates))``.  The module only *holds*
+parameters; all arithmetic runs in the HIP library (no torch compute, no CPU fallback)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import dptr, require_cuda, stream_ptr
+
+
+class AttrDict(dict):
+    """Dict with attribute access -- what reference utils/vocoder/utils.py:77-80 provides."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
+MAX_WAV_VALUE = 32768.0  # reference utils/vocoder/dataset.py:22
+
+
+def get_padding(kernel_size: int, dilation: int = 1) -> int:
+    """reference utils/vocoder/utils.py:44-45"""
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+class _WNConv(nn.Module):
+    """Parameter holder for one weight-normed Conv1d / ConvTranspose1d (keys: bias, weight_g, weight_v
+    -- or bias, weight once weight norm has been removed).  g has shape (dim0,1,1) for both kinds."""
+
+    def __init__(self, shape, n_bias, std=0.01):
+        super().__init__()
+        v = torch.randn(shape) * std
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape(-1, 1, 1))
+        self.weight_v = nn.Parameter(v)
+        self.bias = nn.Parameter(torch.zeros(n_bias))
+
+    def folded(self) -> torch.Tensor:
+        """w = v * (g / ||v||), norm over all dims but 0, on the CPU so the fold is bit-identical to what
+        torch.nn.utils.weight_norm computes in the reference's CPU path."""
+        if "weight" in self._parameters:
+            return self.weight.detach().to("cpu", torch.float32).contiguous()
+        return torch._weight_norm(self.weight_v.detach().to("cpu", torch.float32),
+                                  self.weight_g.detach().to("cpu", torch.float32), 0).contiguous()
+
+    def remove_weight_norm(self):
+        if "weight" in self._parameters:
+            raise ValueError("weight_norm of this layer was already removed")  # torch raises ValueError too
+        w = self.folded().to(self.weight_v.device)
+        del self._parameters["weight_g"], self._parameters["weight_v"]
+        self.weight = nn.Parameter(w)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # accept either representation regardless of which one this module currently holds
+        has_plain = prefix + "weight" in state_dict
+        has_wn = prefix + "weight_g" in state_dict and prefix + "weight_v" in state_dict
+        holds_plain = "weight" in self._parameters
+        if has_plain and not holds_plain:
+            dev = self.weight_v.device
+            del self._parameters["weight_g"], self._parameters["weight_v"]
+            self.weight = nn.Parameter(torch.empty_like(state_dict[prefix + "weight"], device=dev))
+        elif has_wn and holds_plain:
+            dev = self.weight.device
+            del self._parameters["weight"]
+            self.weight_g = nn.Parameter(torch.empty_like(state_dict[prefix + "weight_g"], device=dev))
+            self.weight_v = nn.Parameter(torch.empty_like(state_dict[prefix + "weight_v"], device=dev))
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, kind: str, ch: int, k: int, n_dil: int):
+        super().__init__()
+        self.kind = kind
+        if kind == "1":
+            self.convs1 = nn.ModuleList([_WNConv((ch, ch, k), ch) for _ in range(n_dil)])
+            self.convs2 = nn.ModuleList([_WNConv((ch, ch, k), ch) for _ in range(n_dil)])
+        else:
+            self.convs = nn.ModuleList([_WNConv((ch, ch, k), ch) for _ in range(n_dil)])
+
+    def ordered(self):
+        if self.kind == "1":
+            out = []
+            for a, b in zip(self.convs1, self.convs2):
+                out += [a, b]
+            return out
+        return list(self.convs)
+
+
+class CodeGenerator(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.h = h
+        get = h.get if hasattr(h, "get") else (lambda k, d=None: getattr(h, k, d))
+        self._kind = "1" if str(get("resblock")) == "1" else "2"  # models.py:77: anything but '1' is ResBlock2
+        self._rates = list(get("upsample_rates"))
+        self._up_k = list(get("upsample_kernel_sizes"))
+        self._rb_k = list(get("resblock_kernel_sizes"))
+        self._rb_d = [list(d) for d in get("resblock_dilation_sizes")]
+        self._c0 = int(get("upsample_initial_channel"))
+        self._in_dim = int(get("model_in_dim", 128))
+        self._emb_dim = int(get("embedding_dim"))
+        self._n_emb = int(get("num_embeddings"))
+        self.f0 = get("f0", None)
+        self.multispkr = get("multispkr", None)
+        if self.f0:
+            raise NotImplementedError("f0-conditioned generators are not part of the Parrot-TTS synthesis path")
+        n_dil = {len(d) for d in self._rb_d}
+        if len(n_dil) != 1 or len(self._rb_d) != len(self._rb_k):
+            raise NotImplementedError("resblock_dilation_sizes must give the same number of dilations per kernel size")
+        self._n_dil = n_dil.pop()
+        self.num_kernels = len(self._rb_k)
+        self.num_upsamples = len(self._rates)
+
+        self.conv_pre = _WNConv((self._c0, self._in_dim, 7), self._c0)
+        self.ups = nn.ModuleList()
+        self.resblocks = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(self._rates, self._up_k)):
+            cin, cout = self._c0 // (2 ** i), self._c0 // (2 ** (i + 1))
+            self.ups.append(_WNConv((cin, cout, k), cout))
+        for i in range(len(self._rates)):
+            ch = self._c0 // (2 ** (i + 1))
+            for k in self._rb_k:
+                self.resblocks.append(_ResBlock(self._kind, ch, k, self._n_dil))
+        self.conv_post = _WNConv((1, self._c0 // (2 ** len(self._rates)), 7), 1)
+        self.dict = nn.Embedding(self._n_emb, self._emb_dim)
+        if self.multispkr:
+            self.spkr = nn.Embedding(10, self._emb_dim)
+
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_device = None
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    # ---- parameter bookkeeping ----------------------------------------------------------------
+    def _invalidate(self):
+        if self._handle is not None:
+            _lib.lib().parrot_voc_destroy(self._handle)
+        self._handle, self._ws = None, {}
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        self._invalidate()
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    def _apply(self, fn, recurse=True):
+        self._invalidate()
+        return super()._apply(fn, recurse)
+
+    def remove_weight_norm(self):
+        """reference models.py:113-119 -- afterwards state_dict() has plain ``weight`` keys."""
+        self._invalidate()
+        for m in self._wn_layers():
+            m.remove_weight_norm()
+
+    def _wn_layers(self):
+        out = [self.conv_pre] + list(self.ups)
+        for rb in self.resblocks:
+            out += rb.ordered()
+        return out + [self.conv_post]
+
+    def __del__(self):
+        try:
+            self._invalidate()
+        except Exception:
+            pass
+
+    # ---- HIP handle ---------------------------------------------------------------------------
+    def _build(self, device):
+        if self._in_dim != self._emb_dim * (2 if self.multispkr else 1):
+            raise NotImplementedError("model_in_dim must equal embedding_dim * (1 + multispkr): extra feature streams "
+                                      "(reference models.py:162-167) are not on the synthesis path")
+        cfg = _lib.VocCfg()
+        cfg.num_embeddings, cfg.embedding_dim = self._n_emb, self._emb_dim
+        cfg.multispkr, cfg.n_spkr = int(bool(self.multispkr)), 10
+        cfg.model_in_dim, cfg.upsample_initial_channel = self._in_dim, self._c0
+        cfg.n_stages = len(self._rates)
+        for i, (u, k) in enumerate(zip(self._rates, self._up_k)):
+            cfg.upsample_rates[i], cfg.upsample_kernel_sizes[i] = u, k
+        cfg.n_kernels, cfg.n_dil = len(self._rb_k), self._n_dil
+        for j, k in enumerate(self._rb_k):
+            cfg.resblock_kernel_sizes[j] = k
+            for m, d in enumerate(self._rb_d[j]):
+                cfg.resblock_dilation_sizes[j][m] = d
+        cfg.resblock_type = 1 if self._kind == "1" else 2
+
+        keep = []  # host tensors must outlive parrot_voc_create
+
+        def host(t):
+            t = t.detach().to("cpu", torch.float32).contiguous()
+            keep.append(t)
+            return _lib.fptr(t)
+
+        w = _lib.VocWeights()
+        w.dict = host(self.dict.weight)
+        w.spkr = host(self.spkr.weight) if self.multispkr else None
+        w.conv_pre_w, w.conv_pre_b = host(self.conv_pre.folded()), host(self.conv_pre.bias)
+        for i, up in enumerate(self.ups):
+            w.ups_w[i], w.ups_b[i] = host(up.folded()), host(up.bias)
+        rb_layers = [m for rb in self.resblocks for m in rb.ordered()]
+        arr_t = _lib.c_float_p * len(rb_layers)
+        rb_w, rb_b = arr_t(*[host(m.folded()) for m in rb_layers]), arr_t(*[host(m.bias) for m in rb_layers])
+        w.rb_w, w.rb_b = C.cast(rb_w, C.POINTER(_lib.c_float_p)), C.cast(rb_b, C.POINTER(_lib.c_float_p))
+        w.n_rb = len(rb_layers)
+        w.conv_post_w, w.conv_post_b = host(self.conv_post.folded()), host(self.conv_post.bias)
+        hdl = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().parrot_voc_create(C.byref(hdl), C.byref(cfg), C.byref(w)))
+        self._handle, self._handle_device = hdl, device
+
+    @property
+    def upsample_factor(self) -> int:
+        f = 1
+        for u in self._rates:
+            f *= u
+        return f
+
+    # ---- forward ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, stages: Optional[dict] = None, **kwargs) -> torch.Tensor:
+        extra = [k for k in kwargs if k not in ("code", "spkr", "f0")]
+        if extra or kwargs.get("f0") is not None:
+            raise NotImplementedError(f"extra conditioning features {extra or ['f0']} are not on the synthesis path")
+        code = kwargs["code"]
+        require_cuda(code, "code")
+        if code.dim() != 2 or code.dtype != torch.int64:
+            raise ValueError("code must be a LongTensor of shape (B, U)")
+        dev = code.device
+        spkr = None
+        if self.multispkr:
+            spkr = kwargs["spkr"].to(dev).reshape(-1).contiguous()
+            if spkr.dtype != torch.int64 or spkr.numel() != code.shape[0]:
+                raise ValueError("spkr must be a LongTensor of shape (B, 1)")
+        if self._handle is None or self._handle_device != dev:
+            self._invalidate()
+            self._build(dev)
+        code = code.contiguous()
+        B, U = code.shape
+        lib = _lib.lib()
+        key = (B, U)
+        if key not in self._ws:
+            self._ws = {key: torch.empty(lib.parrot_voc_workspace_bytes(self._handle, B, U), dtype=torch.uint8, device=dev)}
+        ws = self._ws[key]
+        wav = torch.empty((B, 1, U * self.upsample_factor), dtype=torch.float32, device=dev)
+        stage_ptrs = None
+        if stages is not None:  # tests: capture conv_pre / ups_i / mrf_i activations
+            names = ["conv_pre"]
+            T, bufs = U, []
+            bufs.append(torch.empty((B, self._c0, U), dtype=torch.float32, device=dev))
+            for i, u in enumerate(self._rates):
+                T *= u
+                ch = self._c0 // (2 ** (i + 1))
+                names += [f"ups{i}", f"mrf{i}"]
+                bufs += [torch.empty((B, ch, T), dtype=torch.float32, device=dev) for _ in range(2)]
+            stage_ptrs = (C.c_void_p * len(bufs))(*[C.c_void_p(b.data_ptr()) for b in bufs])
+            stages.update(dict(zip(names, bufs)))
+        with torch.cuda.device(dev):
+            _lib.check(lib.parrot_voc_forward(self._handle, dptr(code), dptr(spkr), B, U, dptr(wav), stage_ptrs, dptr(ws),
+                                              ws.numel(), stream_ptr(dev)))
+        return wav
+
+    def check_inputs(self) -> None:
+        """Synchronise and raise IndexError if a unit / speaker id of an earlier forward was out of range
+        (what nn.Embedding raises eagerly in the reference)."""
+        if self._handle is not None:
+            try:
+                _lib.check(_lib.lib().parrot_voc_check(self._handle, stream_ptr(self._handle_device)))
+            except _lib.ParrotHipError as e:
+                if e.code == -2:
+                    raise IndexError(str(e)) from None
+                raise
+
+
+def generate(h, generator: CodeGenerator, code: dict):
+    """Counterpart of reference utils/vocoder/inference.py:65-74: returns (int16 numpy audio, rtf).
+    Unlike the reference the wall time is taken after a stream sync, so the RTF is meaningful on a GPU."""
+    import time
+    dev = code["code"].device
+    torch.cuda.synchronize(dev)
+    start = time.time()
+    y = generator(**code)
+    audio16 = _wav16(y.squeeze())
+    torch.cuda.synchronize(dev)
+    sr = h["sampling_rate"] if isinstance(h, dict) else h.sampling_rate
+    rtf = (time.time() - start) / (y.shape[-1] / sr)
+    return audio16.cpu().numpy(), rtf
+
+
+def _wav16(x):
+    from .ops import wav_to_int16
+    return wav_to_int16(x)

@@ -1,0 +1,307 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): every call goes through the C ABI of
+libparrot_hip.so (via the ctypes shims) and is compared with the CPU oracle / torch CPU ops on the
+same seeded inputs, and with the reference-generated golden vectors.
+
+Tolerances (fp32 path):
+  * single conv layer      : |diff| <= 2e-5 * max|y|   (different summation order only)
+  * vocoder waveform       : max-abs <= 5e-5 of full scale; hard cap 1e-4 (the reference's own
+                             fp32-vs-fp64 error on these weights is 7e-6)
+  * TTE log-durations      : 2e-5 abs;  durations exact where |frac-0.5| > 1e-4
+  * TTE unit ids           : bit-exact where the top-2 logit margin > 1e-4 (all goldens satisfy it)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import parrot_oracle as O  # noqa: E402
+from parrot_tts_amd import ops, synth  # noqa: E402
+from parrot_tts_amd.tte import Parrot  # noqa: E402
+from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
+
+DEV = "cuda:0"
+torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _randn(rng, *shape, scale=1.0):
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def test_mfma_layout_probe():
+    ops.selftest()
+
+
+# ----------------------------------------------------------------------------------------------
+# single layers
+# ----------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # cin, cout, k, dil, B, T, pre, res, act
+    (16, 16, 3, 1, 2, 700, True, True, 0),
+    (16, 16, 11, 5, 1, 1500, True, True, 0),
+    (32, 32, 7, 3, 2, 1000, True, True, 0),
+    (64, 64, 11, 5, 2, 600, True, True, 0),
+    (128, 128, 7, 1, 1, 300, True, False, 0),
+    (256, 256, 3, 5, 2, 200, True, True, 0),
+    (256, 256, 11, 3, 1, 130, True, True, 0),
+    (256, 512, 7, 1, 2, 77, False, False, 0),     # conv_pre shape, ragged T
+    (16, 1, 7, 1, 2, 999, True, False, 2),        # conv_post shape (tanh)
+    (256, 1024, 9, 1, 2, 61, False, False, 1),    # FFN conv1 (relu), T < tile
+    (1024, 256, 1, 1, 2, 61, False, True, 0),     # FFN conv2 (k=1, residual)
+    (256, 768, 1, 1, 3, 23, False, False, 0),     # qkv linear
+    (256, 1000, 1, 1, 2, 40, False, False, 0),    # head (M not a tile multiple)
+    (256, 1, 1, 1, 3, 23, False, False, 0),       # duration proj
+    (20, 24, 5, 2, 2, 50, True, True, 0),         # odd channel counts (zero-padded chunks / rows)
+    (3, 5, 3, 1, 1, 1, False, False, 0),          # T = 1
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4])
+def test_conv1d_matches_torch(case, tile):
+    cin, cout, k, dil, B, T, pre, res, act = case
+    rng = _rng(cin * 131 + cout * 7 + k + dil + T + tile)
+    w = _randn(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
+    b = _randn(rng, cout, scale=0.1)
+    x = _randn(rng, B, cin, T)
+    r = _randn(rng, B, cout, T) if res else None
+    pad = dil * (k - 1) // 2
+    xin = F.leaky_relu(x, 0.1) if pre else x
+    y_ref = F.conv1d(xin, w, b, padding=pad, dilation=dil)
+    if act == 1:
+        y_ref = F.relu(y_ref)
+    elif act == 2:
+        y_ref = torch.tanh(y_ref)
+    if res:
+        y_ref = y_ref + r
+    plan = ops.ConvPlan(w, b, dilation=dil, padding=pad, pre_act=int(pre), pre_slope=0.1, act=act, tile_cfg=tile)
+    y = plan(x.to(DEV), None if r is None else r.to(DEV)).cpu()
+    assert y.shape == y_ref.shape
+    tol = 2e-5 * max(1.0, float(y_ref.abs().max()))
+    assert float((y - y_ref).abs().max()) <= tol
+
+
+def test_conv1d_epilogues_accumulate_like_mrf():
+    rng = _rng(5)
+    C, T, B = 32, 333, 2
+    x = _randn(rng, B, C, T)
+    ws = [_randn(rng, C, C, 3, scale=0.1) for _ in range(3)]
+    bs = [_randn(rng, C, scale=0.1) for _ in range(3)]
+    outs = [F.conv1d(x, w, b, padding=1) + x for w, b in zip(ws, bs)]
+    ref = ((outs[0] + outs[1]) + outs[2]) / 3
+    xs = torch.empty(B, C, T, device=DEV)
+    xd = x.to(DEV)
+    for j, (w, b) in enumerate(zip(ws, bs)):
+        ops.ConvPlan(w, b, padding=1)(xd, xd, out=xs, epilogue=[ops.EPI_STORE, ops.EPI_ADD, ops.EPI_ADD_DIV][j], div=3.0)
+    assert float((xs.cpu() - ref).abs().max()) <= 1e-5
+
+
+CONVT_CASES = [(512, 256, 11, 5, 2, 40), (256, 128, 8, 4, 1, 90), (128, 64, 8, 4, 2, 33), (64, 32, 4, 2, 1, 257),
+               (32, 16, 4, 2, 2, 513), (8, 4, 5, 2, 1, 19), (8, 4, 3, 3, 1, 10), (6, 6, 7, 2, 2, 1)]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_transpose1d_matches_torch(case):
+    cin, cout, k, u, B, T = case
+    rng = _rng(cin + cout * 3 + k * 5 + u)
+    w = _randn(rng, cin, cout, k, scale=1.0 / np.sqrt(cin * k / u))
+    b = _randn(rng, cout, scale=0.1)
+    x = _randn(rng, B, cin, T)
+    p = (k - u) // 2
+    y_ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=p)
+    plan = ops.ConvPlan(w, b, padding=p, transposed=True, stride=u, pre_act=1, pre_slope=0.1)
+    y = plan(x.to(DEV)).cpu()
+    assert y.shape == y_ref.shape
+    assert float((y - y_ref).abs().max()) <= 2e-5 * max(1.0, float(y_ref.abs().max()))
+
+
+def test_wav_to_int16_matches_numpy_cast():
+    rng = _rng(3)
+    w = torch.from_numpy(rng.uniform(-1, 1, size=(3, 4097)).astype(np.float32))
+    w[0, :4] = torch.tensor([0.0, -1.0, 0.99999, -0.99999])
+    got = ops.wav_to_int16(w.to(DEV)).cpu().numpy()
+    assert np.array_equal(got, O.to_int16(w))
+
+
+# ----------------------------------------------------------------------------------------------
+# vocoder
+# ----------------------------------------------------------------------------------------------
+def _voc_cfg(name):
+    if name.startswith("voc_full"):
+        return synth.default_voc_config()
+    h = synth.small_voc_config()
+    if name == "voc_small_singlespk":
+        h["multispkr"] = None
+        h["model_in_dim"] = h["embedding_dim"]
+    if name == "voc_small_resblock2":
+        h["resblock"] = "2"
+        h["resblock_dilation_sizes"] = [[1, 3], [1, 3], [1, 3]]
+    return h
+
+
+def _gen(h, sd):
+    g = CodeGenerator(AttrDict(h))
+    g.load_state_dict(sd)
+    return g.eval().to(DEV)
+
+
+VOC_GOLDENS = ["voc_small", "voc_small_singlespk", "voc_small_resblock2", "voc_full_stages", "voc_full_u40", "voc_full_u40_hot",
+               "voc_full_u256"]
+
+
+@pytest.mark.parametrize("name", VOC_GOLDENS)
+def test_vocoder_matches_reference_golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = json.loads(str(z["meta"]))
+    h = _voc_cfg(name)
+    sd = synth.synth_voc_state_dict(h, seed=m["seed_w"], scale=m["scale"])
+    assert synth.state_digest(sd) == str(z["digest"])
+    g = _gen(h, sd)
+    code, spkr = torch.from_numpy(z["code"]).to(DEV), torch.from_numpy(z["spkr"]).to(DEV)
+    st = {}
+    y = g(code=code, spkr=spkr, stages=st)
+    g.check_inputs()
+    assert y.shape == z["wav"].shape
+    for k in z.files:
+        if k.startswith("stage_"):
+            ref = z[k]
+            got = st[k[6:]].cpu().numpy()
+            assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max()), k
+    err = np.abs(y.cpu().numpy() - z["wav"]).max()
+    assert err <= 5e-5, f"waveform max-abs error {err}"
+    # int16 PCM as the reference driver emits it: allow +-1 LSB where the fp32 error straddles an integer
+    pcm = ops.wav_to_int16(y.squeeze(1)).cpu().numpy().astype(np.int32)
+    assert np.abs(pcm - z["wav_int16"].astype(np.int32)).max() <= 2
+    # weight-norm removed checkpoint (plain `weight` keys) gives the same waveform bit-for-bit
+    g.remove_weight_norm()
+    assert not any(k.endswith("weight_g") for k in g.state_dict())
+    y2 = g(code=code, spkr=spkr)
+    assert torch.equal(y, y2)
+
+
+def test_vocoder_matches_oracle_ragged_shapes():
+    h = synth.small_voc_config()
+    sd = synth.synth_voc_state_dict(h, seed=21, scale=1.0)
+    g = _gen(h, sd)
+    for B, U in [(1, 1), (2, 3), (5, 31), (1, 257)]:
+        batch = synth.synth_voc_batch(B, U, h, seed=B * 100 + U)
+        with torch.no_grad():
+            ref = O.code_generator_forward(sd, h, batch["code"], batch["spkr"])
+        y = g(code=batch["code"].to(DEV), spkr=batch["spkr"].to(DEV)).cpu()
+        assert y.shape == ref.shape
+        assert float((y - ref).abs().max()) <= 5e-5
+    # batch rows are independent: row b of a batch equals the same utterance run alone
+    batch = synth.synth_voc_batch(4, 20, h, seed=77)
+    yb = g(code=batch["code"].to(DEV), spkr=batch["spkr"].to(DEV))
+    y1 = g(code=batch["code"][2:3].to(DEV), spkr=batch["spkr"][2:3].to(DEV))
+    assert torch.equal(yb[2:3], y1)
+
+
+def test_vocoder_rejects_bad_ids_and_cpu_tensors():
+    h = synth.small_voc_config()
+    g = _gen(h, synth.synth_voc_state_dict(h, seed=1))
+    with pytest.raises(RuntimeError):
+        g(code=torch.zeros(1, 4, dtype=torch.int64), spkr=torch.zeros(1, 1, dtype=torch.int64))
+    code = torch.full((1, 4), h["num_embeddings"], dtype=torch.int64, device=DEV)
+    g(code=code, spkr=torch.zeros(1, 1, dtype=torch.int64, device=DEV))
+    with pytest.raises(IndexError):
+        g.check_inputs()
+
+
+# ----------------------------------------------------------------------------------------------
+# TTE
+# ----------------------------------------------------------------------------------------------
+TTE_CASES = {
+    "tte_small_ragged": synth.small_tte_config,
+    "tte_small_multi": synth.small_tte_config,
+    "tte_full_ragged": synth.default_tte_config,
+    "tte_full_forced": synth.default_tte_config,
+}
+
+
+def _parrot(cfg, vocab, n_spk, sd, tmp_path):
+    cfg = synth.clone_config(cfg)
+    cfg["path"]["root_path"] = str(tmp_path)
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({f"s{i}": i for i in range(n_spk)}, f)
+    m = Parrot(cfg, vocab, 0)
+    m.load_state_dict(sd)
+    return m.eval().to(DEV)
+
+
+@pytest.mark.parametrize("name", list(TTE_CASES))
+def test_tte_matches_reference_golden(golden_dir, tmp_path, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = json.loads(str(z["meta"]))
+    cfg = TTE_CASES[name]()
+    sd = synth.synth_tte_state_dict(cfg, m["vocab"], m["n_spk"], seed=m["seed_w"], forced_duration=m["forced"], gain=m["gain"])
+    assert synth.state_digest(sd) == str(z["digest"])
+    model = _parrot(cfg, m["vocab"], m["n_spk"], sd, tmp_path)
+    batch = {"phones": torch.from_numpy(z["phones"]).to(DEV), "src_mask": torch.from_numpy(z["src_mask"]).to(DEV),
+             "speaker": torch.from_numpy(z["speaker"]).to(DEV)}
+    logits, _, tgt_mask, log_dur = model(batch, inference=True)
+    assert np.abs(log_dur.cpu().numpy() - z["log_dur"]).max() <= 2e-5
+    assert np.array_equal(tgt_mask.cpu().numpy(), z["tgt_mask"])
+    r = model.infer_dense(batch)
+    safe = z["half_dist"] > 1e-4
+    assert np.array_equal(r["dur"].cpu().numpy()[safe], z["dur"][safe])
+    assert np.array_equal(r["dur"].cpu().numpy(), z["dur"])  # all goldens are clear of rounding ties
+    n = z["logits_head"].shape[0]
+    msk = z["tgt_mask"][:n]
+    assert np.abs(logits[:n].cpu().numpy() - z["logits_head"])[msk].max() <= 1e-4
+    ids = r["ids"].cpu().numpy()
+    decided = z["tgt_mask"] & (z["margin"] > 1e-4)
+    assert np.array_equal(ids[decided], z["ids"][decided])
+    assert decided[z["tgt_mask"]].mean() > 0.999
+    rag = model.infer(batch)
+    for b, row in enumerate(rag):
+        ln = int(z["ids_ragged_len"][b])
+        assert row == z["ids_ragged"][b, :ln].tolist()  # includes the Q2 extra id per short row
+
+
+def test_tte_matches_oracle_other_shapes(tmp_path):
+    cfg = synth.small_tte_config()
+    for (B, S, n_spk, seed) in [(1, 1, 1, 0), (2, 5, 2, 1), (7, 33, 3, 2)]:
+        d = tmp_path / f"c{seed}"
+        d.mkdir()
+        sd = synth.synth_tte_state_dict(cfg, 30, n_spk, seed=seed)
+        model = _parrot(cfg, 30, n_spk, sd, d)
+        batch = synth.synth_tte_batch(B, S, 30, n_spk, seed=seed + 10, ragged=True)
+        with torch.no_grad():
+            ref = O.tte_forward(sd, cfg, batch)
+            ref_ids = O.tte_infer(sd, cfg, batch)
+        if ref["logits"].shape[1] == 0:
+            continue
+        gb = {k: v.to(DEV) for k, v in batch.items()}
+        logits, _, tgt_mask, log_dur = model(gb, inference=True)
+        assert float((log_dur.cpu() - ref["log_dur"]).abs().max()) <= 2e-5
+        assert torch.equal(tgt_mask.cpu(), ref["tgt_mask"])
+        m = ref["tgt_mask"]
+        assert float((logits.cpu() - ref["logits"])[m].abs().max()) <= 1e-4
+        assert model.infer(gb) == ref_ids
+
+
+def test_tte_error_behaviour(tmp_path):
+    cfg = synth.small_tte_config()
+    sd = synth.synth_tte_state_dict(cfg, 30, 1, seed=0)
+    model = _parrot(cfg, 30, 1, sd, tmp_path)
+    batch = {k: v.to(DEV) for k, v in synth.synth_tte_batch(1, cfg["transformer"]["max_len"], 30, 1, seed=0).items()}
+    with pytest.raises(IndexError):      # pe[T] out of range, reference modules/fft.py:18
+        model.infer(batch)
+    bad = {k: v.to(DEV) for k, v in synth.synth_tte_batch(1, 4, 30, 1, seed=0).items()}
+    bad["phones"][0, 1] = 30
+    with pytest.raises(IndexError):      # nn.Embedding IndexError in the reference
+        model.infer(bad)
+    model.train()
+    with pytest.raises(AssertionError):  # reference modules/parrot.py:113
+        model.infer(bad)
+    with pytest.raises(NotImplementedError):
+        model(bad, inference=False)
