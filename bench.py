@@ -61,7 +61,8 @@ def cpu_baseline(cfg, h, tsd, vsd, B, S, vocab, n_spk):
     """The oracle (CPU restatement, parity-pinned to the reference) timed on this host's cores on a bounded
     sample of the same workload: B utterances of the full pipeline."""
     from oracle import parrot_oracle as O
-    cores = os.cpu_count() or 1
+    # more threads than ~64 only adds oversubscription on these layer sizes (256 threads: 100 s / pass)
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=0)
     folded = O.fold_weight_norm(vsd)

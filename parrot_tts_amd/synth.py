@@ -105,10 +105,22 @@ def sinusoid_table(max_len: int, d_model: int) -> torch.Tensor:
     return pe
 
 
+def patch_pe_rows(sd: Dict[str, torch.Tensor], idx, rows) -> None:
+    """Overwrite rows ``idx`` of ``pos_emb.pe`` with the exact values a golden run used (only rows S and L
+    are ever read: reference quirk Q1)."""
+    for i, r in zip(idx, rows):
+        sd["pos_emb.pe"][int(i)] = torch.as_tensor(r)
+
+
 def state_digest(sd: Dict[str, torch.Tensor]) -> str:
-    """sha256 over (key, shape, raw bytes) of every tensor, in sorted key order."""
+    """sha256 over (key, shape, raw bytes) of every tensor, in sorted key order.
+
+    ``pos_emb.pe`` is skipped: it is rebuilt with torch.sin/cos/exp, whose last bit depends on the
+    host CPU's vector ISA; goldens carry the two rows they used instead (``patch_pe_rows``)."""
     hsh = hashlib.sha256()
     for k in sorted(sd):
+        if k == "pos_emb.pe":
+            continue
         t = sd[k].detach().cpu().contiguous()
         hsh.update(k.encode())
         hsh.update(str(tuple(t.shape)).encode())

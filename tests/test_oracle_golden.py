@@ -34,6 +34,7 @@ def test_tte_oracle_matches_reference(golden_dir, name):
     cfg = TTE_CASES[name]()
     sd = synth.synth_tte_state_dict(cfg, m["vocab"], m["n_spk"], seed=m["seed_w"], forced_duration=m["forced"], gain=m["gain"])
     assert synth.state_digest(sd) == str(z["digest"]), "synthetic weights did not regenerate identically"
+    synth.patch_pe_rows(sd, z["pe_idx"], z["pe_rows"])
     batch = {"phones": torch.from_numpy(z["phones"]), "src_mask": torch.from_numpy(z["src_mask"]),
              "speaker": torch.from_numpy(z["speaker"])}
     gen = synth.synth_tte_batch(m["B"], m["S"], m["vocab"], m["n_spk"], seed=m["seed_in"], ragged=m["ragged"])

@@ -99,6 +99,7 @@ def tte_case(name, cfg, vocab, n_spk, B, S, seed_w, seed_in, ragged, forced=None
         tgt_mask=tgt_mask.numpy(), ids=ids.numpy(), margin=margin.numpy(), ids_ragged=rag,
         ids_ragged_len=np.array([len(r) for r in ids_ragged]),
         logits_head=logits[:keep_logits_rows].numpy(),
+        pe_idx=np.array([S, logits.shape[1]]), pe_rows=sd["pos_emb.pe"][[S, logits.shape[1]]].numpy(),
     )
 
 
