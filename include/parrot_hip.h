@@ -74,6 +74,8 @@ int parrot_conv_num_tile_cfgs(void);
 /* Optional per-launch timing of the conv kernel with HIP events on the launch stream, aggregated
  * per tile configuration (bench.py's roofline object).  prof_end fills out[cfg*4 + {0..3}] =
  * {launches, total ms, algorithmic FLOPs, algorithmic bytes} for n_cfg configurations.         */
+/* dst[i] = src[i], 4 bytes per lane: known-byte-count kernel for calibrating the HBM PMC counters. */
+int parrot_debug_copy(const float* src, float* dst, size_t n, void* stream);
 int parrot_prof_begin(void);
 int parrot_prof_end(double* out, int32_t n_cfg);
 

@@ -716,6 +716,15 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
     return PARROT_OK;
 }
 
+// plain dword copy (dst[i] = src[i]): the known-byte-count kernel used to calibrate the rocprofv3
+// FETCH_SIZE / WRITE_SIZE counters for this library's 4-byte-per-lane access pattern.
+extern "C" int parrot_debug_copy(const float* src, float* dst, size_t n, void* stream) {
+    if (!src || !dst) return fail(PARROT_E_INVALID, "debug_copy: null argument");
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    HIP_TRY(hipGetLastError());
+    return PARROT_OK;
+}
+
 // device-side input-range flag (bad unit / speaker / phone ids <-> the reference's Embedding IndexError).
 // Synchronises the stream; returns 0 or PARROT_E_RANGE and clears the flag.
 static int read_flag(int* err, hipStream_t s, const char* who) {
