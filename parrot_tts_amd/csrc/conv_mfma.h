@@ -62,17 +62,21 @@ struct ConvParams {
     long res_bstride;
     int groups;          // grouped conv: Cin is PER GROUP, rows [g*Mg, (g+1)*Mg) read channels [g*Cin, (g+1)*Cin)
     int Mg;              // rows per group (multiple of the block's BM when groups > 1)
+    int u_inv16;         // ceil(65536 / u)
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_TANH) return tanhf(v);
-    return v;
+// ACT_TANH (conv_post only) is applied by tanh_inplace_kernel right after the conv launch: inlining tanhf
+// 64x into this epilogue costs ~40 VGPRs and a wave of occupancy.
+__device__ __forceinline__ float apply_act(float v, int act) { return (act == ACT_RELU && v < 0.f) ? 0.f : v; }
+
+__global__ void tanh_inplace_kernel(float* __restrict__ y, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = tanhf(y[i]);
 }
 
 // WAVES_M x WAVES_N waves, each owning WM x WN MFMA tiles of 32x32; CI input channels per LDS slab.
 template <int WAVES_M, int WAVES_N, int WM, int WN, int CI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 3) void conv_mfma_kernel(const ConvParams p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
@@ -101,19 +105,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
 
     float stage[ROWS_PW][COLS_IT];
 
+    // Branch-free slab load: the address is clamped into the row (always mapped), masked values become 0.
     auto load_slab = [&](int c) {
 #pragma unroll
         for (int r = 0; r < ROWS_PW; ++r) {
             const int ch = c * CI + wave * ROWS_PW + r;
-            const float* __restrict__ row = xb + (size_t)ch * p.Tin;
+            const bool chok = ch < p.Cin;
+            const float* __restrict__ row = xb + (size_t)(chok ? ch : 0) * p.Tin;
 #pragma unroll
             for (int i = 0; i < COLS_IT; ++i) {
                 const int col = lane + 64 * i;
                 const int tin = t0 - p.pad_left + col;
-                float v = 0.f;
-                if (col < W && ch < p.Cin && tin >= 0 && tin < p.Tin) v = row[tin];
-                if (p.pre == PRE_LRELU) v = v > 0.f ? v : v * p.pre_slope;
-                stage[r][i] = v;
+                const bool ok = chok && col < W && tin >= 0 && tin < p.Tin;
+                float v = row[ok ? tin : 0];
+                v = ok ? v : 0.f;
+                const float vs = v * p.pre_slope;
+                stage[r][i] = (p.pre == PRE_LRELU && v < 0.f) ? vs : v;
             }
         }
     };
@@ -186,35 +193,78 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
         __syncthreads();
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const size_t ybase = (size_t)b * p.y_bstride;
-    const size_t rbase = (size_t)b * p.res_bstride;
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
+    if (p.u > 1) {
+        // transposed conv: GEMM row m = o*u + phase, column n = input step -> out[o][n*u + phase]; stores only.
+        // o = m / u via a 16-bit reciprocal of the small in-tile remainder (exact for rem < 64, u <= 64).
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int mbase = blockIdx.y * BM + (wm * WM + mt) * 32 + 4 * half;
+            const int o0 = mbase / p.u, rem0 = mbase - o0 * p.u;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) {
+                const int n = t0 + (wn * WN + nt) * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cr = (r & 3) + 8 * (r >> 2);
+                    const int rem = rem0 + cr;
+                    const int dq = (rem * p.u_inv16) >> 16;
+                    const int o = o0 + dq;
+                    const int tau = n * p.u + (rem - dq * p.u);
+                    const bool ok = (mbase + cr < p.M) && (n < p.Ncols) && (tau < p.Tout);
+                    const float v = acc[mt][nt][r] + ((p.bias && ok) ? p.bias[o] : 0.f);
+                    if (ok) yb[o * p.Tout + tau] = apply_act(v, p.act);
+                }
+            }
+        }
+        return;
+    }
+    // plain conv: per half tile (8 rows) issue all residual / accumulate loads first so they are in flight
+    // together (masked lanes read element 0, always mapped), then finish branch-free and store.
+    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    const bool has_acc = p.epi != EPI_STORE;
+    const bool do_div = p.epi == EPI_ADD_DIV;
+    const float act_lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
+        const int mbase = blockIdx.y * BM + (wm * WM + mt) * 32 + 4 * half;
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
             const int n = t0 + (wn * WN + nt) * 32 + l31;
+            const bool colok = n < p.Ncols;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = blockIdx.y * BM + (wm * WM + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && n < p.Ncols) {
-                    int o = m, tau = n;
-                    if (p.u > 1) {
-                        o = m / p.u;
-                        tau = n * p.u + (m - o * p.u);
-                    }
-                    if (tau < p.Tout) {
-                        float v = acc[mt][nt][r];
-                        if (p.bias) v += p.bias[o];
-                        v = apply_act(v, p.act);
-                        const size_t off = (size_t)o * p.Tout + tau;
-                        const size_t idx = ybase + off;
-                        if (p.res) v += p.res[rbase + off];
-                        if (p.epi == EPI_ADD) v = p.y[idx] + v;
-                        else if (p.epi == EPI_ADD_DIV) v = (p.y[idx] + v) / p.div;
-                        p.y[idx] = v;
-                    }
+            for (int g = 0; g < 2; ++g) {
+                int off[8];
+                float rv[8], yv[8], bs[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = g * 8 + q;
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const bool ok = colok && m < p.M;
+                    off[q] = ok ? m * p.Tout + n : -1;
+                    bs[q] = (p.bias && ok) ? p.bias[m] : 0.f;
+                    rv[q] = 0.f;
+                    yv[q] = 0.f;
                 }
+                if (rb) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rv[q] = rb[off[q] < 0 ? 0 : off[q]];
+                }
+                if (has_acc) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) yv[q] = yb[off[q] < 0 ? 0 : off[q]];
+                }
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = yv[q] + (fmaxf(acc[mt][nt][g * 8 + q] + bs[q], act_lo) + rv[q]);
+                if (do_div) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = v[q] / p.div;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (off[q] >= 0) yb[off[q]] = v[q];
             }
         }
     }

@@ -139,6 +139,7 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
     c->Cin = d->c_in / groups;
     int dmin = 0;
     if (d->transposed) {
+        if (d->stride > 64) return fail(PARROT_E_UNSUPPORTED, "conv_create: transposed stride > 64");
         if (groups != 1 || d->dilation != 1 || d->stride <= 0) return fail(PARROT_E_UNSUPPORTED, "conv_create: transposed conv needs groups=1, dilation=1");
         // polyphase gather form: output tau = t*u + r uses taps kappa = r + p - delta*u, input t + delta
         const int u = d->stride, p = d->padding, k = d->k;
@@ -224,7 +225,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.k = c->kk; p.dil = c->dil; p.pad_left = c->pad_left;
     p.nchunks = c->nchunks; p.n_it = c->n_it;
     p.pre = c->d.pre_act; p.pre_slope = c->d.pre_slope; p.act = c->d.act;
-    p.epi = epi; p.div = div; p.u = c->u;
+    p.epi = epi; p.div = div; p.u = c->u; p.u_inv16 = (65536 + c->u - 1) / c->u;
     p.groups = c->groups; p.Mg = c->Mg;
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
@@ -252,6 +253,11 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         HIP_TRY(hipEventRecord(rec.a, s));
     }
     HIP_TRY(launch_conv(cfg, p, s));
+    if (c->d.act == ACT_TANH) {  // dense (B, Cout, Tout) output assumed for the tanh layers (conv_post)
+        const size_t n = (size_t)B * c->Cout * Tout;
+        hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n);
+        HIP_TRY(hipGetLastError());
+    }
     if (g_prof_on) {
         HIP_TRY(hipEventRecord(rec.b, s));
         g_prof.push_back(rec);
