@@ -36,8 +36,8 @@ from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 HBM_PEAK_GBS = 8000.0
 SAMPLE_RATE = 16000             # reference utils/vocoder/config.json:32 (the metric's "22.05 kHz" does not match the reference)
-TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16>", "conv_mfma_kernel<1,4,2,2,16>", "conv_mfma_kernel<1,4,1,4,16>",
-              "conv_mfma_kernel<2,2,2,2,32>", "conv_mfma_kernel<2,2,2,1,16>"]
+TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>", "conv_mfma_kernel<1,4,1,4,16,2>",
+              "conv_mfma_kernel<2,2,2,2,32,3>", "conv_mfma_kernel<2,2,2,1,16,3>"]
 
 
 def pmc_traffic(kernel: str):

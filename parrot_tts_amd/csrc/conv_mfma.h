@@ -74,9 +74,10 @@ __global__ void tanh_inplace_kernel(float* __restrict__ y, size_t n) {
     if (i < n) y[i] = tanhf(y[i]);
 }
 
-// WAVES_M x WAVES_N waves, each owning WM x WN MFMA tiles of 32x32; CI input channels per LDS slab.
-template <int WAVES_M, int WAVES_N, int WM, int WN, int CI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 3) void conv_mfma_kernel(const ConvParams p) {
+// WAVES_M x WAVES_N waves, each owning WM x WN MFMA tiles of 32x32; CI input channels per LDS slab;
+// MINW = workgroups per CU the register allocation must leave room for (LDS caps the 32x512 tile at 2).
+template <int WAVES_M, int WAVES_N, int WM, int WN, int CI, int MINW>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_mfma_kernel(const ConvParams p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
@@ -136,13 +137,43 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 3) void conv_mfma_kernel(con
         }
     };
 
+    // Accumulators start at bias (+ residual): the residual tile is fetched here, in the prologue, where its
+    // latency hides behind the first slab load, instead of in the epilogue where every co-resident workgroup
+    // would sit in a memory phase at the same time (they run in lockstep).  Folding needs act == none.
+    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
+    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    const bool plain = p.u == 1;
+    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
     f32x16 acc[WM][WN];
+    // pass 1: every residual element goes straight into its own accumulator register, so all WM*WN*16 loads are
+    // in flight together (clamped addresses; masked lanes are never stored); pass 2 adds the bias.
 #pragma unroll
-    for (int mt = 0; mt < WM; ++mt)
+    for (int mt = 0; mt < WM; ++mt) {
+        const int mbase = blockIdx.y * BM + (wm * WM + mt) * 32 + 4 * half;
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt)
+        for (int nt = 0; nt < WN; ++nt) {
+            const int n = t0 + (wn * WN + nt) * 32 + l31;
+            const bool colok = n < p.Ncols;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                acc[mt][nt][r] = fold_res ? rb[(colok && m < p.M) ? m * p.Tout + n : 0] : 0.f;
+            }
+        }
+    }
+    if (plain && p.bias) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int mbase = blockIdx.y * BM + (wm * WM + mt) * 32 + 4 * half;
+            float bsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsv[r] = p.bias[min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1)];
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bsv[r];
+        }
+    }
 
     // A-fragment stream: one 1 KiB group (64 lanes x float4) per (chunk, tap, q) per m-tile.
     const f32x4* __restrict__ aptr[WM];
@@ -162,31 +193,47 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 3) void conv_mfma_kernel(con
     // per-lane LDS read base: row (half) of the channel pair, column of this lane in the wave's N range
     const int bbase = half * RS + wn * (WN * 32) + l31;
     int it = 0;
+    float bv_cur[4][WN], bv_nxt[4][WN];
     for (int c = 0; c < p.nchunks; ++c) {
         const float* __restrict__ xs = smem + (c & 1) * (CI * RS) + bbase;
         const bool more = (c + 1 < p.nchunks);
         if (more) load_slab(c + 1);
+        // operands of the chunk's first iteration (one exposed LDS latency per chunk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) bv_cur[e][nt] = xs[(2 * e) * RS + nt * 32];
         for (int j = 0; j < p.k; ++j) {
             const float* __restrict__ xj = xs + j * p.dil;
 #pragma unroll
             for (int q = 0; q < QN; ++q) {
                 ++it;
+                // software pipeline: fetch the NEXT iteration's A group (L2) and B values (LDS) before this
+                // iteration's 16*WM*WN/4 MFMAs; the sched_barrier keeps hipcc from sinking them to their use.
+                // (after the chunk's last iteration the B prefetch reads in-row garbage that is discarded)
+                const float* __restrict__ xn = (q + 1 < QN) ? xj + 8 * (q + 1) * RS : xj + p.dil;
 #pragma unroll
                 for (int mt = 0; mt < WM; ++mt) {
                     a_cur[mt] = a_nxt[mt];
                     a_nxt[mt] = aptr[mt][(size_t)it * 64];  // wfrag is padded by one group at the end
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float bv[WN];
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int nt = 0; nt < WN; ++nt) bv[nt] = xj[(8 * q + 2 * e) * RS + nt * 32];
+                    for (int nt = 0; nt < WN; ++nt) bv_nxt[e][nt] = xn[(2 * e) * RS + nt * 32];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < WN; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][e], bv[nt], acc[mt][nt], 0, 0, 0);
-                }
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][e], bv_cur[e][nt], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt) bv_cur[e][nt] = bv_nxt[e][nt];
             }
         }
         if (more) store_slab((c + 1) & 1);
@@ -194,7 +241,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 3) void conv_mfma_kernel(con
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
     if (p.u > 1) {
         // transposed conv: GEMM row m = o*u + phase, column n = input step -> out[o][n*u + phase]; stores only.
         // o = m / u via a 16-bit reciprocal of the small in-tile remainder (exact for rem < 64, u <= 64).
@@ -220,9 +266,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 3) void conv_mfma_kernel(con
         }
         return;
     }
-    // plain conv: per half tile (8 rows) issue all residual / accumulate loads first so they are in flight
-    // together (masked lanes read element 0, always mapped), then finish branch-free and store.
-    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    // plain conv (bias and, when folded, the residual are already inside acc): per half tile (8 rows) issue the
+    // remaining loads together (masked lanes read element 0, always mapped), finish branch-free, store.
+    const bool late_res = rb != nullptr && !fold_res;
     const bool has_acc = p.epi != EPI_STORE;
     const bool do_div = p.epi == EPI_ADD_DIV;
     const float act_lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
@@ -236,18 +282,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 3) void conv_mfma_kernel(con
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 int off[8];
-                float rv[8], yv[8], bs[8];
+                float rv[8], yv[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int r = g * 8 + q;
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const bool ok = colok && m < p.M;
-                    off[q] = ok ? m * p.Tout + n : -1;
-                    bs[q] = (p.bias && ok) ? p.bias[m] : 0.f;
+                    off[q] = (colok && m < p.M) ? m * p.Tout + n : -1;
                     rv[q] = 0.f;
                     yv[q] = 0.f;
                 }
-                if (rb) {
+                if (late_res) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) rv[q] = rb[off[q] < 0 ? 0 : off[q]];
                 }
@@ -257,7 +301,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 3) void conv_mfma_kernel(con
                 }
                 float v[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = yv[q] + (fmaxf(acc[mt][nt][g * 8 + q] + bs[q], act_lo) + rv[q]);
+                for (int q = 0; q < 8; ++q) v[q] = yv[q] + (fmaxf(acc[mt][nt][g * 8 + q], act_lo) + rv[q]);
                 if (do_div) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] = v[q] / p.div;
@@ -285,9 +329,9 @@ __host__ inline TileCfg tile_cfg(int id) {
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int CI>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int CI, int MINW>
 inline hipError_t launch_conv_t(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, WM, WN, CI>;
+    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, WM, WN, CI, MINW>;
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in (gfx950 has 160 KiB per CU)
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -303,11 +347,11 @@ inline hipError_t launch_conv(int cfg, const ConvParams& p, hipStream_t s) {
     dim3 grid(p.tiles_n * p.B, (p.M + t.bm - 1) / t.bm);
     const size_t lds = (size_t)2 * t.ci * (t.bn + CONV_HALO) * sizeof(float);
     switch (cfg) {
-        case 0: return launch_conv_t<2, 2, 2, 2, 16>(p, grid, lds, s);
-        case 1: return launch_conv_t<1, 4, 2, 2, 16>(p, grid, lds, s);
-        case 2: return launch_conv_t<1, 4, 1, 4, 16>(p, grid, lds, s);
-        case 3: return launch_conv_t<2, 2, 2, 2, 32>(p, grid, lds, s);
-        default: return launch_conv_t<2, 2, 2, 1, 16>(p, grid, lds, s);
+        case 0: return launch_conv_t<2, 2, 2, 2, 16, 3>(p, grid, lds, s);
+        case 1: return launch_conv_t<1, 4, 2, 2, 16, 3>(p, grid, lds, s);
+        case 2: return launch_conv_t<1, 4, 1, 4, 16, 2>(p, grid, lds, s);
+        case 3: return launch_conv_t<2, 2, 2, 2, 32, 3>(p, grid, lds, s);
+        default: return launch_conv_t<2, 2, 2, 1, 16, 3>(p, grid, lds, s);
     }
 }
 

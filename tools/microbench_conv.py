@@ -27,9 +27,13 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tiles", type=str, default="-1,0,1,2,3")
+    ap.add_argument("--layers", type=str, default="", help="comma separated layer names (default: all)")
     a = ap.parse_args()
     dev = "cuda:0"
+    want = set(a.layers.split(",")) if a.layers else None
     for name, cin, cout, k, dil, T in LAYERS:
+        if want is not None and name not in want:
+            continue
         w = torch.randn(cout, cin, k) / (cin * k) ** 0.5
         b = torch.randn(cout) * 0.1
         x = torch.randn(a.batch, cin, T, device=dev)
