@@ -61,7 +61,18 @@ typedef struct {
     float pre_slope;
     int32_t act;                               /* 0 none, 1 relu, 2 tanh (applied to bias+sum)   */
     int32_t tile_cfg;                          /* -1 = auto; else index into the tile table      */
+    int32_t precision;                         /* PARROT_PREC_*; -1 = library default            */
 } parrot_conv_desc;
+
+/* How fp32 products are evaluated.  Inputs, outputs, residuals and accumulation are fp32 in both modes.
+ *   PARROT_PREC_F32    v_mfma_f32_32x32x2_f32: exact fp32 fma chain.
+ *   PARROT_PREC_BF16X6 each operand split into 3 bf16 pieces, 6 bf16 MFMAs per product group (terms below
+ *                      2^-23 of the product dropped), fp32 accumulate: fp32-class error at 16/6 the MFMA rate;
+ *                      used for layers with >= 64 output channels, the rest stays on the exact kernel.
+ * Default: PARROT_PRECISION env ("f32" | "bf16x6") at first use, else f32; or set it here before *_create. */
+#define PARROT_PREC_F32 0
+#define PARROT_PREC_BF16X6 1
+int parrot_set_default_precision(int32_t prec);
 
 int parrot_conv_create(parrot_conv_t** out, const parrot_conv_desc* d, const float* w_host, const float* bias_host);
 void parrot_conv_destroy(parrot_conv_t*);

@@ -21,7 +21,7 @@ class ParrotHipError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [("c_in", C.c_int32), ("c_out", C.c_int32), ("k", C.c_int32), ("dilation", C.c_int32),
                 ("padding", C.c_int32), ("transposed", C.c_int32), ("stride", C.c_int32), ("pre_act", C.c_int32),
-                ("pre_slope", C.c_float), ("act", C.c_int32), ("tile_cfg", C.c_int32)]
+                ("pre_slope", C.c_float), ("act", C.c_int32), ("tile_cfg", C.c_int32), ("precision", C.c_int32)]
 
 
 class VocCfg(C.Structure):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "parrot_abi_version": (C.c_int, []),
     "parrot_last_error": (C.c_char_p, []),
     "parrot_selftest": (C.c_int, [vp]),
+    "parrot_set_default_precision": (C.c_int, [i32]),
     "parrot_conv_create": (C.c_int, [C.POINTER(vp), C.POINTER(ConvDesc), c_float_p, c_float_p]),
     "parrot_conv_destroy": (None, [vp]),
     "parrot_conv_run": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),

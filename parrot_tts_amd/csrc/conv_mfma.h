@@ -74,6 +74,132 @@ __global__ void tanh_inplace_kernel(float* __restrict__ y, size_t n) {
     if (i < n) y[i] = tanhf(y[i]);
 }
 
+// ---- shared by every conv kernel variant: accumulator init (bias + folded residual) and epilogue --------------
+// m_wave / n_wave: first GEMM row / column of this wave's tile block; C/D layout of the 32x32 MFMA shapes:
+// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) (identical for the f32 and bf16 instructions).
+template <int WM, int WN>
+__device__ __forceinline__ void conv_acc_init(const ConvParams& p, f32x16 (&acc)[WM][WN], int b, int m_wave, int n_wave, int half,
+                                              int l31) {
+    // Accumulators start at bias (+ residual): the residual tile is fetched here, in the prologue, where its
+    // latency hides behind the first slab load, instead of in the epilogue where every co-resident workgroup
+    // would sit in a memory phase at the same time (they run in lockstep).  Folding needs act == none.
+    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
+    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    const bool plain = p.u == 1;
+    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
+    // pass 1: every residual element goes straight into its own accumulator register, so all WM*WN*16 loads are
+    // in flight together (clamped addresses; masked lanes are never stored); pass 2 adds the bias.
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int mbase = m_wave + mt * 32 + 4 * half;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const int n = n_wave + nt * 32 + l31;
+            const bool colok = n < p.Ncols;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                acc[mt][nt][r] = fold_res ? rb[(colok && m < p.M) ? m * p.Tout + n : 0] : 0.f;
+            }
+        }
+    }
+    if (plain && p.bias) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int mbase = m_wave + mt * 32 + 4 * half;
+            float bsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsv[r] = p.bias[min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1)];
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bsv[r];
+        }
+    }
+
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[WM][WN], int b, int m_wave, int n_wave, int half,
+                                              int l31) {
+    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
+    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    const bool plain = p.u == 1;
+    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    if (p.u > 1) {
+        // transposed conv: GEMM row m = o*u + phase, column n = input step -> out[o][n*u + phase]; stores only.
+        // o = m / u via a 16-bit reciprocal of the small in-tile remainder (exact for rem < 64, u <= 64).
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int mbase = m_wave + mt * 32 + 4 * half;
+            const int o0 = mbase / p.u, rem0 = mbase - o0 * p.u;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) {
+                const int n = n_wave + nt * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cr = (r & 3) + 8 * (r >> 2);
+                    const int rem = rem0 + cr;
+                    const int dq = (rem * p.u_inv16) >> 16;
+                    const int o = o0 + dq;
+                    const int tau = n * p.u + (rem - dq * p.u);
+                    const bool ok = (mbase + cr < p.M) && (n < p.Ncols) && (tau < p.Tout);
+                    const float v = acc[mt][nt][r] + ((p.bias && ok) ? p.bias[o] : 0.f);
+                    if (ok) yb[o * p.Tout + tau] = apply_act(v, p.act);
+                }
+            }
+        }
+        return;
+    }
+    // plain conv (bias and, when folded, the residual are already inside acc): per half tile (8 rows) issue the
+    // remaining loads together (masked lanes read element 0, always mapped), finish branch-free, store.
+    const bool late_res = rb != nullptr && !fold_res;
+    const bool has_acc = p.epi != EPI_STORE;
+    const bool do_div = p.epi == EPI_ADD_DIV;
+    const float act_lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int mbase = m_wave + mt * 32 + 4 * half;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const int n = n_wave + nt * 32 + l31;
+            const bool colok = n < p.Ncols;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                int off[8];
+                float rv[8], yv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = g * 8 + q;
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    off[q] = (colok && m < p.M) ? m * p.Tout + n : -1;
+                    rv[q] = 0.f;
+                    yv[q] = 0.f;
+                }
+                if (late_res) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rv[q] = rb[off[q] < 0 ? 0 : off[q]];
+                }
+                if (has_acc) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) yv[q] = yb[off[q] < 0 ? 0 : off[q]];
+                }
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = yv[q] + (fmaxf(acc[mt][nt][g * 8 + q], act_lo) + rv[q]);
+                if (do_div) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = v[q] / p.div;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (off[q] >= 0) yb[off[q]] = v[q];
+            }
+        }
+    }
+}
+
 // WAVES_M x WAVES_N waves, each owning WM x WN MFMA tiles of 32x32; CI input channels per LDS slab;
 // MINW = workgroups per CU the register allocation must leave room for (LDS caps the 32x512 tile at 2).
 template <int WAVES_M, int WAVES_N, int WM, int WN, int CI, int MINW>
@@ -137,43 +263,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_mfma_kernel(
         }
     };
 
-    // Accumulators start at bias (+ residual): the residual tile is fetched here, in the prologue, where its
-    // latency hides behind the first slab load, instead of in the epilogue where every co-resident workgroup
-    // would sit in a memory phase at the same time (they run in lockstep).  Folding needs act == none.
-    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
-    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
-    const bool plain = p.u == 1;
-    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
     f32x16 acc[WM][WN];
-    // pass 1: every residual element goes straight into its own accumulator register, so all WM*WN*16 loads are
-    // in flight together (clamped addresses; masked lanes are never stored); pass 2 adds the bias.
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt) {
-        const int mbase = blockIdx.y * BM + (wm * WM + mt) * 32 + 4 * half;
-#pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-            const int n = t0 + (wn * WN + nt) * 32 + l31;
-            const bool colok = n < p.Ncols;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                acc[mt][nt][r] = fold_res ? rb[(colok && m < p.M) ? m * p.Tout + n : 0] : 0.f;
-            }
-        }
-    }
-    if (plain && p.bias) {
-#pragma unroll
-        for (int mt = 0; mt < WM; ++mt) {
-            const int mbase = blockIdx.y * BM + (wm * WM + mt) * 32 + 4 * half;
-            float bsv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bsv[r] = p.bias[min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1)];
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bsv[r];
-        }
-    }
+    const int m_wave = blockIdx.y * BM + wm * WM * 32;
+    const int n_wave = t0 + wn * WN * 32;
+    conv_acc_init<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 
     // A-fragment stream: one 1 KiB group (64 lanes x float4) per (chunk, tap, q) per m-tile.
     const f32x4* __restrict__ aptr[WM];
@@ -240,78 +333,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_mfma_kernel(
         __syncthreads();
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    if (p.u > 1) {
-        // transposed conv: GEMM row m = o*u + phase, column n = input step -> out[o][n*u + phase]; stores only.
-        // o = m / u via a 16-bit reciprocal of the small in-tile remainder (exact for rem < 64, u <= 64).
-#pragma unroll
-        for (int mt = 0; mt < WM; ++mt) {
-            const int mbase = blockIdx.y * BM + (wm * WM + mt) * 32 + 4 * half;
-            const int o0 = mbase / p.u, rem0 = mbase - o0 * p.u;
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt) {
-                const int n = t0 + (wn * WN + nt) * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cr = (r & 3) + 8 * (r >> 2);
-                    const int rem = rem0 + cr;
-                    const int dq = (rem * p.u_inv16) >> 16;
-                    const int o = o0 + dq;
-                    const int tau = n * p.u + (rem - dq * p.u);
-                    const bool ok = (mbase + cr < p.M) && (n < p.Ncols) && (tau < p.Tout);
-                    const float v = acc[mt][nt][r] + ((p.bias && ok) ? p.bias[o] : 0.f);
-                    if (ok) yb[o * p.Tout + tau] = apply_act(v, p.act);
-                }
-            }
-        }
-        return;
-    }
-    // plain conv (bias and, when folded, the residual are already inside acc): per half tile (8 rows) issue the
-    // remaining loads together (masked lanes read element 0, always mapped), finish branch-free, store.
-    const bool late_res = rb != nullptr && !fold_res;
-    const bool has_acc = p.epi != EPI_STORE;
-    const bool do_div = p.epi == EPI_ADD_DIV;
-    const float act_lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt) {
-        const int mbase = blockIdx.y * BM + (wm * WM + mt) * 32 + 4 * half;
-#pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-            const int n = t0 + (wn * WN + nt) * 32 + l31;
-            const bool colok = n < p.Ncols;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                int off[8];
-                float rv[8], yv[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = g * 8 + q;
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    off[q] = (colok && m < p.M) ? m * p.Tout + n : -1;
-                    rv[q] = 0.f;
-                    yv[q] = 0.f;
-                }
-                if (late_res) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) rv[q] = rb[off[q] < 0 ? 0 : off[q]];
-                }
-                if (has_acc) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) yv[q] = yb[off[q] < 0 ? 0 : off[q]];
-                }
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = yv[q] + (fmaxf(acc[mt][nt][g * 8 + q], act_lo) + rv[q]);
-                if (do_div) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = v[q] / p.div;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (off[q] >= 0) yb[off[q]] = v[q];
-            }
-        }
-    }
+    conv_epilogue<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 }
 
 // tile table (index = parrot_conv_desc.tile_cfg)

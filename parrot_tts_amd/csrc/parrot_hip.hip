@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "attn.h"
+#include "conv_bf16x6.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 
@@ -110,8 +111,12 @@ struct parrot_conv {
     int nchunks = 0, n_it = 0;
     float* wfrag = nullptr;
     float* bias = nullptr;
+    int prec = 0;              // 0: exact fp32 MFMA, 1: split-bf16 (6 bf16 MFMAs per product group, fp32 accumulate)
+    uint16_t* wfrag16 = nullptr;
+    int n_it16 = 0;
 
     ~parrot_conv() {
+        if (wfrag16) (void)hipFree(wfrag16);
         if (wfrag) (void)hipFree(wfrag);
         if (bias) (void)hipFree(bias);
     }
@@ -120,6 +125,33 @@ struct parrot_conv {
         return (Tin - 1) * d.stride - 2 * d.padding + d.k;
     }
 };
+
+static int g_default_prec = -1;
+static int default_prec() {
+    if (g_default_prec < 0) {
+        const char* e = getenv("PARROT_PRECISION");
+        g_default_prec = (e && (!strcmp(e, "bf16x6") || !strcmp(e, "1"))) ? 1 : 0;
+    }
+    return g_default_prec;
+}
+extern "C" int parrot_set_default_precision(int32_t prec) {
+    if (prec != 0 && prec != 1) return fail(PARROT_E_INVALID, "set_default_precision: 0 (fp32 MFMA) or 1 (bf16x6)");
+    g_default_prec = prec;
+    return PARROT_OK;
+}
+
+static inline uint16_t bf16_rn_host(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 
 static int choose_cfg(int M, int k) {
     if (M <= 32) return 2;
@@ -201,8 +233,50 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
                             g[lane * 4 + e] = v;
                         }
                 }
-    HIP_TRY(hipMalloc((void**)&c->wfrag, nfl * sizeof(float)));
-    HIP_TRY(hipMemcpy(c->wfrag, pk.data(), nfl * sizeof(float), hipMemcpyHostToDevice));
+    // weight accessor shared by both packings: W'(m, i, j) of the GEMM view (0 outside the real extents)
+    auto wval = [&](int m, int i, int j) -> float {
+        if (m >= c->M || i >= Cing) return 0.f;
+        if (d->transposed) {
+            const int o = m / c->u, r = m % c->u;
+            const int kap = r + d->padding - (j + dmin) * c->u;
+            return (kap >= 0 && kap < k) ? w[((size_t)i * d->c_out + o) * k + kap] : 0.f;
+        }
+        return w[((size_t)m * Cing + i) * k + j];
+    };
+    const int want_prec = (d->precision >= 0) ? d->precision : default_prec();
+    if (want_prec == 1 && c->Mg >= 64 && d->tile_cfg < 0) {
+        // split-bf16 plan: 16 channels per chunk, one MFMA k-step per tap; [m_tile][chunk*tap][piece][lane][8]
+        c->prec = 1;
+        c->cfg = (c->Mg <= 64) ? 1 : 0;
+        const TileCfg t16 = tile_cfg(c->cfg);
+        if (groups > 1 && c->Mg % t16.bm) return fail(PARROT_E_UNSUPPORTED, "conv_create: rows per group must be a multiple of the tile height");
+        c->nchunks = (c->Cin + 15) / 16;
+        c->n_it16 = c->nchunks * c->kk;
+        const int mt16 = (c->M + t16.bm - 1) / t16.bm * (t16.bm / 32);
+        const size_t n16 = ((size_t)mt16 * c->n_it16 + 1) * 1536;  // 3 pieces x 64 lanes x 8 bf16 per step (+1 pad step)
+        std::vector<uint16_t> pk16(n16, 0);
+        for (int mt = 0; mt < mt16; ++mt)
+            for (int ch = 0; ch < c->nchunks; ++ch)
+                for (int j = 0; j < c->kk; ++j) {
+                    uint16_t* g = pk16.data() + ((size_t)mt * c->n_it16 + (size_t)ch * c->kk + j) * 1536;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = wval(mt * 32 + (lane & 31), ch * 16 + 8 * (lane >> 5) + e, j);
+                            const uint16_t h1 = bf16_rn_host(v);
+                            const float r1 = v - bf16_to_f(h1);
+                            const uint16_t h2 = bf16_rn_host(r1);
+                            const uint16_t h3 = bf16_rn_host(r1 - bf16_to_f(h2));
+                            g[0 * 512 + lane * 8 + e] = h1;
+                            g[1 * 512 + lane * 8 + e] = h2;
+                            g[2 * 512 + lane * 8 + e] = h3;
+                        }
+                }
+        HIP_TRY(hipMalloc((void**)&c->wfrag16, n16 * sizeof(uint16_t)));
+        HIP_TRY(hipMemcpy(c->wfrag16, pk16.data(), n16 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMalloc((void**)&c->wfrag, nfl * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->wfrag, pk.data(), nfl * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (bias) {
         HIP_TRY(hipMalloc((void**)&c->bias, (size_t)d->c_out * sizeof(float)));
         HIP_TRY(hipMemcpy(c->bias, bias, (size_t)d->c_out * sizeof(float), hipMemcpyHostToDevice));
@@ -231,7 +305,11 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
     p.res_bstride = res_bstride > 0 ? res_bstride : p.y_bstride;
     int cfg = c->cfg;
-    if ((cfg == 0 || cfg == 3) && p.Ncols <= 64 && tile_cfg(4).ci == tile_cfg(cfg).ci) cfg = 4;  // same packing, narrower tile
+    if (c->prec == 0 && (cfg == 0 || cfg == 3) && p.Ncols <= 64 && tile_cfg(4).ci == tile_cfg(cfg).ci) cfg = 4;  // same packing, narrower tile
+    if (c->prec == 1) {
+        p.wfrag = reinterpret_cast<const float*>(c->wfrag16);
+        p.n_it = c->n_it16;
+    }
     const TileCfg t = tile_cfg(cfg);
     p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
     ProfRec rec{};
@@ -247,12 +325,12 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         // algorithmic work of the layer (real taps only; DESIGN.md "roofline accounting")
         const double macs = (double)B * c->d.c_out * c->Cin * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         const double elems = (double)B * ((double)c->d.c_in * Tin + (double)c->Cout * Tout * (1 + (res ? 1 : 0) + (epi != EPI_STORE ? 1 : 0)));
-        rec.cfg = cfg;
+        rec.cfg = (c->prec == 1) ? NUM_TILE_CFGS + cfg : cfg;  // rows 5, 6 = the bf16x6 kernels
         rec.flops = 2.0 * macs;
         rec.bytes = 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k);
         HIP_TRY(hipEventRecord(rec.a, s));
     }
-    HIP_TRY(launch_conv(cfg, p, s));
+    HIP_TRY(c->prec == 1 ? launch_conv_bf16x6(cfg, p, s) : launch_conv(cfg, p, s));
     if (c->d.act == ACT_TANH) {  // dense (B, Cout, Tout) output assumed for the tanh layers (conv_post)
         const size_t n = (size_t)B * c->Cout * Tout;
         hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n);
@@ -331,7 +409,7 @@ static int make_conv(std::unique_ptr<parrot_conv>& slot, int cin, int cout, int 
                      int pre, float slope, int act, const float* w, const float* b, int groups = 1) {
     parrot_conv_desc d{};
     d.c_in = cin; d.c_out = cout; d.k = k; d.dilation = dil; d.padding = pad; d.transposed = transposed; d.stride = stride;
-    d.pre_act = pre; d.pre_slope = slope; d.act = act; d.tile_cfg = -1;
+    d.pre_act = pre; d.pre_slope = slope; d.act = act; d.tile_cfg = -1; d.precision = -1;
     parrot_conv* c = nullptr;
     TRY(conv_build(&c, &d, groups, w, b));
     slot.reset(c);

@@ -14,6 +14,12 @@ from . import _lib
 PRE_NONE, PRE_LRELU = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 EPI_STORE, EPI_ADD, EPI_ADD_DIV = 0, 1, 2
+PREC_F32, PREC_BF16X6 = 0, 1
+
+
+def set_default_precision(prec: int) -> None:
+    """Library-wide default for handles created afterwards (PREC_F32 exact fp32 MFMA, PREC_BF16X6 split-bf16)."""
+    _lib.check(_lib.lib().parrot_set_default_precision(int(prec)))
 
 
 def stream_ptr(device=None) -> C.c_void_p:
@@ -41,13 +47,13 @@ class ConvPlan:
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, dilation: int = 1, padding: int = 0,
                  transposed: bool = False, stride: int = 1, pre_act: int = PRE_NONE, pre_slope: float = 0.0,
-                 act: int = ACT_NONE, tile_cfg: int = -1):
+                 act: int = ACT_NONE, tile_cfg: int = -1, precision: int = -1):
         w = weight.detach().to("cpu", torch.float32).contiguous()
         b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
         c_in, c_out = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
         self.c_in, self.c_out = int(c_in), int(c_out)
         d = _lib.ConvDesc(self.c_in, self.c_out, int(w.shape[2]), int(dilation), int(padding), int(bool(transposed)), int(stride),
-                          int(pre_act), float(pre_slope), int(act), int(tile_cfg))
+                          int(pre_act), float(pre_slope), int(act), int(tile_cfg), int(precision))
         self._h = C.c_void_p()
         _lib.check(_lib.lib().parrot_conv_create(C.byref(self._h), C.byref(d), _lib.fptr(w), None if b is None else _lib.fptr(b)))
 

@@ -44,7 +44,7 @@ def test_abi_basics(lib):
 
 def test_struct_sizes_match_header():
     from parrot_tts_amd import _lib
-    assert ctypes.sizeof(_lib.ConvDesc) == 11 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 12 * 4
     assert ctypes.sizeof(_lib.TteCfg) == 14 * 4
     n_int = 7 + 8 + 8 + 1 + 4 + 1 + 16 + 1
     assert ctypes.sizeof(_lib.VocCfg) == n_int * 4

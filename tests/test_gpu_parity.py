@@ -53,6 +53,16 @@ def test_mfma_layout_probe():
     ops.selftest()
 
 
+@pytest.fixture(params=["f32", "bf16x6"])
+def prec(request):
+    """Run a model-level test under both product-evaluation modes of the conv kernel (include/parrot_hip.h
+    PARROT_PREC_*): exact fp32 MFMA, and the split-bf16 scheme (fp32 data, 6 bf16 MFMAs per product group).
+    Both are held to the SAME tolerances."""
+    ops.set_default_precision(ops.PREC_BF16X6 if request.param == "bf16x6" else ops.PREC_F32)
+    yield request.param
+    ops.set_default_precision(ops.PREC_F32)
+
+
 # ----------------------------------------------------------------------------------------------
 # single layers
 # ----------------------------------------------------------------------------------------------
@@ -102,6 +112,31 @@ def test_conv1d_matches_torch(case, tile):
     assert float((y - y_ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] >= 64], ids=lambda c: "x".join(map(str, c)))
+def test_conv1d_bf16x6_matches_torch(case):
+    cin, cout, k, dil, B, T, pre, res, act = case
+    rng = _rng(cin * 31 + cout * 17 + k + dil + T)
+    w = _randn(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
+    b = _randn(rng, cout, scale=0.1)
+    x = _randn(rng, B, cin, T)
+    r = _randn(rng, B, cout, T) if res else None
+    pad = dil * (k - 1) // 2
+    y_ref = F.conv1d((F.leaky_relu(x, 0.1) if pre else x).double(), w.double(), b.double(), padding=pad, dilation=dil)
+    if act == 1:
+        y_ref = F.relu(y_ref)
+    if res:
+        y_ref = y_ref + r.double()
+    args = dict(dilation=dil, padding=pad, pre_act=int(pre), pre_slope=0.1, act=act)
+    xd, rd = x.to(DEV), None if r is None else r.to(DEV)
+    y6 = ops.ConvPlan(w, b, precision=ops.PREC_BF16X6, **args)(xd, rd).cpu().double()
+    y32 = ops.ConvPlan(w, b, precision=ops.PREC_F32, **args)(xd, rd).cpu().double()
+    scale = max(1.0, float(y_ref.abs().max()))
+    e6, e32 = float((y6 - y_ref).abs().max()) / scale, float((y32 - y_ref).abs().max()) / scale
+    _report(test="conv_bf16x6_vs_fp64", case="x".join(map(str, case)), err_bf16x6=e6, err_f32_mfma=e32)
+    assert e6 <= 2e-5
+    assert e6 <= 4 * e32 + 1e-6, "split-bf16 evaluation must stay in the same error class as the exact fp32 kernel"
+
+
 def test_conv1d_epilogues_accumulate_like_mrf():
     rng = _rng(5)
     C, T, B = 32, 333, 2
@@ -121,8 +156,9 @@ CONVT_CASES = [(512, 256, 11, 5, 2, 40), (256, 128, 8, 4, 1, 90), (128, 64, 8, 4
                (32, 16, 4, 2, 2, 513), (8, 4, 5, 2, 1, 19), (8, 4, 3, 3, 1, 10), (6, 6, 7, 2, 2, 1)]
 
 
+@pytest.mark.parametrize("precision", [0, 1])
 @pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_transpose1d_matches_torch(case):
+def test_conv_transpose1d_matches_torch(case, precision):
     cin, cout, k, u, B, T = case
     rng = _rng(cin + cout * 3 + k * 5 + u)
     w = _randn(rng, cin, cout, k, scale=1.0 / np.sqrt(cin * k / u))
@@ -130,7 +166,7 @@ def test_conv_transpose1d_matches_torch(case):
     x = _randn(rng, B, cin, T)
     p = (k - u) // 2
     y_ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=p)
-    plan = ops.ConvPlan(w, b, padding=p, transposed=True, stride=u, pre_act=1, pre_slope=0.1)
+    plan = ops.ConvPlan(w, b, padding=p, transposed=True, stride=u, pre_act=1, pre_slope=0.1, precision=precision)
     y = plan(x.to(DEV)).cpu()
     assert y.shape == y_ref.shape
     assert float((y - y_ref).abs().max()) <= 2e-5 * max(1.0, float(y_ref.abs().max()))
@@ -171,7 +207,7 @@ VOC_GOLDENS = ["voc_small", "voc_small_singlespk", "voc_small_resblock2", "voc_f
 
 
 @pytest.mark.parametrize("name", VOC_GOLDENS)
-def test_vocoder_matches_reference_golden(golden_dir, name):
+def test_vocoder_matches_reference_golden(golden_dir, name, prec):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     m = json.loads(str(z["meta"]))
     h = _voc_cfg(name)
@@ -189,7 +225,7 @@ def test_vocoder_matches_reference_golden(golden_dir, name):
             got = st[k[6:]].cpu().numpy()
             assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max()), k
     err = float(np.abs(y.cpu().numpy() - z["wav"]).max())
-    _report(test="vocoder_golden", name=name, wav_max_abs_err=err)
+    _report(test="vocoder_golden", name=name, precision=prec, wav_max_abs_err=err)
     assert err <= (5e-4 if name.endswith("_hot") else 5e-5), f"waveform max-abs error {err}"
     # int16 PCM as the reference driver emits it: allow +-1 LSB where the fp32 error straddles an integer
     pcm = ops.wav_to_int16(y.squeeze(1)).cpu().numpy().astype(np.int32)
@@ -201,7 +237,7 @@ def test_vocoder_matches_reference_golden(golden_dir, name):
     assert torch.equal(y, y2)
 
 
-def test_vocoder_matches_oracle_ragged_shapes():
+def test_vocoder_matches_oracle_ragged_shapes(prec):
     h = synth.small_voc_config()
     sd = synth.synth_voc_state_dict(h, seed=21, scale=1.0)
     g = _gen(h, sd)
@@ -252,7 +288,7 @@ def _parrot(cfg, vocab, n_spk, sd, tmp_path):
 
 
 @pytest.mark.parametrize("name", list(TTE_CASES))
-def test_tte_matches_reference_golden(golden_dir, tmp_path, name):
+def test_tte_matches_reference_golden(golden_dir, tmp_path, name, prec):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     m = json.loads(str(z["meta"]))
     cfg = TTE_CASES[name]()
@@ -264,7 +300,7 @@ def test_tte_matches_reference_golden(golden_dir, tmp_path, name):
              "speaker": torch.from_numpy(z["speaker"]).to(DEV)}
     logits, _, tgt_mask, log_dur = model(batch, inference=True)
     n_ = z["logits_head"].shape[0]
-    _report(test="tte_golden", name=name, log_dur_max_abs_err=float(np.abs(log_dur.cpu().numpy() - z["log_dur"]).max()),
+    _report(test="tte_golden", name=name, precision=prec, log_dur_max_abs_err=float(np.abs(log_dur.cpu().numpy() - z["log_dur"]).max()),
             logits_max_abs_err=float(np.abs(logits[:n_].cpu().numpy() - z["logits_head"])[z["tgt_mask"][:n_]].max()),
             min_margin=float(z["margin"][z["tgt_mask"]].min()))
     assert np.abs(log_dur.cpu().numpy() - z["log_dur"]).max() <= 2e-5
@@ -296,7 +332,7 @@ def _enc_out(sd, cfg, batch):
     return out
 
 
-def test_tte_matches_oracle_other_shapes(tmp_path):
+def test_tte_matches_oracle_other_shapes(tmp_path, prec):
     cfg = synth.small_tte_config()
     for (B, S, n_spk, seed) in [(1, 1, 1, 0), (1, 2, 1, 4), (2, 5, 2, 1), (7, 33, 3, 2), (3, 70, 2, 3)]:
         d = tmp_path / f"c{seed}"
