@@ -37,8 +37,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 HBM_PEAK_GBS = 8000.0
 SAMPLE_RATE = 16000             # reference utils/vocoder/config.json:32 (the metric's "22.05 kHz" does not match the reference)
 TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>", "conv_mfma_kernel<1,4,1,4,16,2>",
-              "conv_mfma_kernel<2,2,2,2,32,3>", "conv_mfma_kernel<2,2,2,1,16,3>",
-              "conv_bf16x6_kernel<2,2,2,2,2>", "conv_bf16x6_kernel<1,4,2,2,2>"]
+              "conv_mfma_kernel<2,2,2,2,32,3>", "conv_mfma_kernel<2,2,2,1,16,3>", "conv_mfma_kernel<1,4,1,2,16,4>",
+              "conv_bf16x6_kernel<2,2,2,2,2>", "conv_bf16x6_kernel<1,4,2,2,2>", "resblock_fused_kernel"]
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the split scheme spends 6 bf16 MFMA FMAs per algorithmic fp32 FMA
 
 
@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--workload", choices=["full", "vocoder"], default="full")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-fp32 pass")
     ap.add_argument("--precision", choices=["f32", "bf16x6"], default=os.environ.get("PARROT_BENCH_PRECISION", "bf16x6"),
                     help="product evaluation of the conv kernel for layers with >= 64 output channels (fp32 data either way)")
     a = ap.parse_args()
@@ -125,54 +126,58 @@ def main():
     torch.cuda.set_device(dev)
     vocab, n_spk = 300, 10
     from parrot_tts_amd import ops
-    ops.set_default_precision(ops.PREC_BF16X6 if a.precision == "bf16x6" else ops.PREC_F32)
-    cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
-    pipe = SynthesisPipeline(parrot, gen)
+    lib = _lib.lib()
     B, S = a.batch, a.src_len
-    batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(B, S, vocab, n_spk, seed=rank).items()}
-    vb = {k: v.to(dev) for k, v in synth.synth_voc_batch(B, 4 * S, h, seed=rank).items()}
-
-    def step():
-        if a.workload == "full":
-            out = pipe(batch)
-            wav = out["wav"]
-        else:
-            wav = gen(code=vb["code"], spkr=vb["spkr"])
-        return pdist.gather_waveforms(wav, dst=0) if world > 1 else wav
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        wav = step()
-    fence()
-    lib = _lib.lib()
-    lib.parrot_prof_begin()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wav = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = (C.c_double * (4 * len(TILE_NAMES)))()
-    _lib.check(lib.parrot_prof_end(prof, len(TILE_NAMES)))
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    def run(precision, steps, warmup):
+        """Build both models under `precision`, then W untimed + K timed steps.  Returns (max-over-ranks seconds,
+        per-kernel profile rows, last gathered waveform batch on rank 0, model pieces for the CPU baseline)."""
+        ops.set_default_precision(ops.PREC_BF16X6 if precision == "bf16x6" else ops.PREC_F32)
+        cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
+        pipe = SynthesisPipeline(parrot, gen)
+        batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(B, S, vocab, n_spk, seed=rank).items()}
+        vb = {k: v.to(dev) for k, v in synth.synth_voc_batch(B, 4 * S, h, seed=rank).items()}
 
-    if rank == 0:
-        n_samples_step = world * B * (wav.shape[-1] if wav is not None else 0)
-        ms = elapsed / a.steps * 1e3
-        value = n_samples_step / (ms / 1e3)
+        def step():
+            wav = pipe(batch)["wav"] if a.workload == "full" else gen(code=vb["code"], spkr=vb["spkr"])
+            return pdist.gather_waveforms(wav, dst=0) if world > 1 else wav
+
+        wav = None
+        for _ in range(warmup):
+            wav = step()
+        fence()
+        lib.parrot_prof_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wav = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = (C.c_double * (4 * len(TILE_NAMES)))()
+        _lib.check(lib.parrot_prof_end(prof, len(TILE_NAMES)))
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
         rows = []
         for i, nm in enumerate(TILE_NAMES):
             n, tms, fl, by = prof[4 * i: 4 * i + 4]
             if n > 0:
-                rows.append({"kernel": nm, "launches_per_step": n / a.steps, "avg_us": tms / n * 1e3, "ms_per_step": tms / a.steps,
+                rows.append({"kernel": nm, "launches_per_step": n / steps, "avg_us": tms / n * 1e3, "ms_per_step": tms / steps,
                              "tflops": fl / tms / 1e9, "alg_gbs": by / tms / 1e6})
         rows.sort(key=lambda r: -r["ms_per_step"])
+        n_samples = world * B * (wav.shape[-1] if wav is not None else 4 * S * 320)
+        del pipe, parrot, gen
+        return float(t.item()), rows, n_samples, (cfg, h, tsd, vsd)
+
+    elapsed, rows, n_samples_step, pieces = run(a.precision, a.steps, a.warmup)
+
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        value = n_samples_step / (ms / 1e3)
         dom = rows[0]
         traffic, traffic_src = pmc_traffic(dom["kernel"])
         split = dom["kernel"].startswith("conv_bf16x6")
@@ -197,7 +202,16 @@ def main():
                        "note": "reference vocoder is 16 kHz / 320 samples per unit (utils/vocoder/config.json:24,32), not 22.05 kHz"},
             "roofline": roof,
         }
+    if world == 1 and a.precision == "bf16x6" and not a.no_alt:
+        # the same workload with every product on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32), for reference
+        e2, rows2, n2, _ = run("f32", min(a.steps, 5), 1)
+        ms2 = e2 / min(a.steps, 5) * 1e3
+        res["exact_fp32_mfma"] = {"value": n2 / (ms2 / 1e3), "unit": "samples/s", "ms_per_step": ms2, "steps": min(a.steps, 5),
+                                  "dominant_kernel": rows2[0]["kernel"], "dominant_tflops": rows2[0]["tflops"],
+                                  "frac_of_fp32_mfma_peak": rows2[0]["tflops"] / FP32_MFMA_PEAK_TFLOPS}
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
+            cfg, h, tsd, vsd = pieces
             res["cpu_baseline"] = cpu_baseline(cfg, h, tsd, vsd, a.cpu_batch, S, vocab, n_spk)
         print(json.dumps(res))
     if world > 1:

@@ -67,6 +67,7 @@ SIGNATURES = {
     "parrot_last_error": (C.c_char_p, []),
     "parrot_selftest": (C.c_int, [vp]),
     "parrot_set_default_precision": (C.c_int, [i32]),
+    "parrot_set_fused_resblocks": (C.c_int, [i32]),
     "parrot_conv_create": (C.c_int, [C.POINTER(vp), C.POINTER(ConvDesc), c_float_p, c_float_p]),
     "parrot_conv_destroy": (None, [vp]),
     "parrot_conv_run": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),

@@ -25,18 +25,20 @@ namespace parrot {
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned bf16_rn_bits(float x) {  // round-to-nearest-even, finite inputs
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair (x0 in the low half), round-to-nearest-even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pk_bf16(float x0, float x1) {
+    const f32x2 v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-// x -> three bf16 pieces (bit patterns) with x ~= p0 + p1 + p2
-__device__ __forceinline__ void split3(float x, unsigned& p0, unsigned& p1, unsigned& p2) {
-    p0 = bf16_rn_bits(x);
-    const float r1 = x - __uint_as_float(p0 << 16);
-    p1 = bf16_rn_bits(r1);
-    const float r2 = r1 - __uint_as_float(p1 << 16);
-    p2 = bf16_rn_bits(r2);
+// (x0, x1) -> three packed bf16 pairs with x ~= p0 + p1 + p2 (each subtraction is exact in fp32)
+__device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(p1 << 16), s1 = r1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(s0, s1);
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW>
@@ -93,15 +95,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
             const int item = tid + NT * i;
             const int oct = item / COLS;
             const int col = item - oct * COLS;
-            unsigned q0[8], q1[8], q2[8];
+            unsigned q0[4], q1[4], q2[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split3(stage[i][e], q0[e], q1[e], q2[e]);
+            for (int e = 0; e < 4; ++e) split3_pk(stage[i][2 * e], stage[i][2 * e + 1], q0[e], q1[e], q2[e]);
             if (oct < 2) {
-                uint4 v0, v1, v2;
-                v0.x = q0[0] | (q0[1] << 16); v0.y = q0[2] | (q0[3] << 16); v0.z = q0[4] | (q0[5] << 16); v0.w = q0[6] | (q0[7] << 16);
-                v1.x = q1[0] | (q1[1] << 16); v1.y = q1[2] | (q1[3] << 16); v1.z = q1[4] | (q1[5] << 16); v1.w = q1[6] | (q1[7] << 16);
-                v2.x = q2[0] | (q2[1] << 16); v2.y = q2[2] | (q2[3] << 16); v2.z = q2[4] | (q2[5] << 16); v2.w = q2[6] | (q2[7] << 16);
-                const int off = col * 32 + oct * 16;
+                const uint4 v0 = {q0[0], q0[1], q0[2], q0[3]}, v1 = {q1[0], q1[1], q1[2], q1[3]}, v2 = {q2[0], q2[1], q2[2], q2[3]};
+                // the two channel octets of a column swap places on odd 8-column groups: with a 32 B column
+                // stride this makes every ds_read_b128 lane group hit 16 distinct 16 B slots (no 2-way conflict)
+                const int off = col * 32 + ((oct ^ ((col >> 3) & 1)) * 16);
                 *reinterpret_cast<uint4*>(dst + off) = v0;
                 *reinterpret_cast<uint4*>(dst + PIECE_BYTES + off) = v1;
                 *reinterpret_cast<uint4*>(dst + 2 * PIECE_BYTES + off) = v2;
@@ -114,50 +115,61 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     const int n_wave = t0 + wn * WN * 32;
     conv_acc_init<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 
-    // A stream: n_it = nchunks * k steps per m-tile, 3 KiB per step ([piece][lane][8 bf16])
+    // A stream: n_it = nchunks * k steps per m-tile, 3 KiB per step ([piece][lane][8 bf16]).
+    // Chunks are visited in an order rotated by the tile index: workgroups running side by side then stream
+    // DIFFERENT weight lines at any moment instead of all hammering the same L2 channel in lockstep (the order
+    // depends on the column tile only, so a batch row's result does not depend on the batch it sits in).
     const char* __restrict__ aptr[WM];
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
         const int mtg = blockIdx.y * (BM / 32) + wm * WM + mt;
         aptr[mt] = reinterpret_cast<const char*>(p.wfrag) + ((size_t)mtg * p.n_it) * 3072 + lane * 16;
     }
+    const int rot = tn % p.nchunks;
     s16x8 a_cur[WM][3], a_nxt[WM][3], b_cur[WN][3], b_nxt[WN][3];
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) a_nxt[mt][pc] = *reinterpret_cast<const s16x8*>(aptr[mt] + pc * 1024);
+        for (int pc = 0; pc < 3; ++pc) a_nxt[mt][pc] = *reinterpret_cast<const s16x8*>(aptr[mt] + (size_t)(rot * p.k) * 3072 + pc * 1024);
 
-    load_slab(0);
+    load_slab(rot);
     store_slab(0);
     __syncthreads();
 
-    const int bbase = (wn * WN * 32 + l31) * 32 + half * 16;  // byte offset of this lane's fragment at tap 0
-    int it = 0;
+    const int colbase = wn * WN * 32 + l31;  // this lane's column at tap 0 (tile nt adds 32*nt: same swizzle bit)
+    auto b_off = [&](int col) { return col * 32 + ((half ^ ((col >> 3) & 1)) * 16); };
+    int cc = rot;  // current chunk
     for (int c = 0; c < p.nchunks; ++c) {
-        const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES + bbase;
+        const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
         const bool more = (c + 1 < p.nchunks);
-        if (more) load_slab(c + 1);
+        const int cn = (cc + 1 == p.nchunks) ? 0 : cc + 1;  // next chunk in rotated order
+        if (more && !(p.ablate & 4)) load_slab(cn);
+        {
+            const int o0 = b_off(colbase);
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt)
+            for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) b_cur[nt][pc] = *reinterpret_cast<const s16x8*>(xs + pc * PIECE_BYTES + nt * 1024);
+                for (int pc = 0; pc < 3; ++pc) b_cur[nt][pc] = *reinterpret_cast<const s16x8*>(xs + pc * PIECE_BYTES + nt * 1024 + o0);
+        }
         for (int j = 0; j < p.k; ++j) {
-            ++it;
             // prefetch the next step's operands (after the chunk's last tap the B prefetch reads in-slab garbage
-            // that is discarded; wfrag carries one padding step at the end)
-            const char* __restrict__ xn = xs + (j + 1) * p.dil * 32;
+            // that is discarded; after the very last step the A prefetch re-reads a valid step and is discarded)
+            const int step_n = (j + 1 < p.k) ? cc * p.k + j + 1 : cn * p.k;
+            const int on = b_off(colbase + (j + 1) * p.dil);
 #pragma unroll
             for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
                     a_cur[mt][pc] = a_nxt[mt][pc];
-                    a_nxt[mt][pc] = *reinterpret_cast<const s16x8*>(aptr[mt] + (size_t)it * 3072 + pc * 1024);
+                    if (!(p.ablate & 1)) a_nxt[mt][pc] = *reinterpret_cast<const s16x8*>(aptr[mt] + (size_t)step_n * 3072 + pc * 1024);
                 }
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) b_nxt[nt][pc] = *reinterpret_cast<const s16x8*>(xn + pc * PIECE_BYTES + nt * 1024);
+                for (int pc = 0; pc < 3; ++pc)
+                    if (!(p.ablate & 2)) b_nxt[nt][pc] = *reinterpret_cast<const s16x8*>(xs + pc * PIECE_BYTES + nt * 1024 + on);
             __builtin_amdgcn_sched_barrier(0);
+            if (!(p.ablate & 8))
 #pragma unroll
             for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
@@ -176,8 +188,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) b_cur[nt][pc] = b_nxt[nt][pc];
         }
-        if (more) store_slab((c + 1) & 1);
+        if (more && !(p.ablate & 4)) store_slab((c + 1) & 1);
         __syncthreads();
+        cc = cn;
     }
     conv_epilogue<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 }
@@ -198,11 +211,25 @@ inline hipError_t launch_conv_bf16x6_t(const ConvParams& p, dim3 grid, hipStream
     return hipGetLastError();
 }
 
-inline hipError_t launch_conv_bf16x6(int cfg, const ConvParams& p, hipStream_t s) {
-    const TileCfg t = tile_cfg(cfg);
-    dim3 grid(p.tiles_n * p.B, (p.M + t.bm - 1) / t.bm);
-    if (cfg == 1) return launch_conv_bf16x6_t<1, 4, 2, 2, 2>(p, grid, s);
-    return launch_conv_bf16x6_t<2, 2, 2, 2, 2>(p, grid, s);
+// bf16x6 tile variants: 0/1 = 128x128 / 64x256 (wave 64x64, 2 waves per SIMD);
+//                      2/3 = 128x256 / 64x512 (wave 64x128, 1 wave per SIMD: half the weight traffic per MFMA)
+//                      4   = 32x512 (waves 1x4, wave 32x128) for 32-row layers
+inline void bf16x6_tile(int variant, int& bm, int& bn) {
+    if (variant == 4) { bm = 32; bn = 512; return; }
+    bm = (variant & 1) ? 64 : 128;
+    bn = (variant & 1) ? ((variant & 2) ? 512 : 256) : ((variant & 2) ? 256 : 128);
+}
+inline hipError_t launch_conv_bf16x6(int variant, const ConvParams& p, hipStream_t s) {
+    int bm, bn;
+    bf16x6_tile(variant, bm, bn);
+    dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
+    switch (variant) {
+        case 1: return launch_conv_bf16x6_t<1, 4, 2, 2, 2>(p, grid, s);
+        case 2: return launch_conv_bf16x6_t<2, 2, 2, 4, 1>(p, grid, s);
+        case 3: return launch_conv_bf16x6_t<1, 4, 2, 4, 1>(p, grid, s);
+        case 4: return launch_conv_bf16x6_t<1, 4, 1, 4, 2>(p, grid, s);
+        default: return launch_conv_bf16x6_t<2, 2, 2, 2, 2>(p, grid, s);
+    }
 }
 
 }  // namespace parrot

@@ -63,6 +63,7 @@ struct ConvParams {
     int groups;          // grouped conv: Cin is PER GROUP, rows [g*Mg, (g+1)*Mg) read channels [g*Cin, (g+1)*Cin)
     int Mg;              // rows per group (multiple of the block's BM when groups > 1)
     int u_inv16;         // ceil(65536 / u)
+    int ablate;          // debug only (PARROT_ABLATE): bit0 no A loads, bit1 no B reads, bit2 no slab staging, bit3 no MFMA
 };
 
 // ACT_TANH (conv_post only) is applied by tanh_inplace_kernel right after the conv launch: inlining tanhf
@@ -340,13 +341,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_mfma_kernel(
 struct TileCfg {
     int bm, bn, ci, threads;
 };
-constexpr int NUM_TILE_CFGS = 5;
+constexpr int NUM_TILE_CFGS = 6;
 __host__ inline TileCfg tile_cfg(int id) {
     switch (id) {
         case 0: return {128, 128, 16, 256};  // waves 2x2, wave 64x64
         case 1: return {64, 256, 16, 256};   // waves 1x4, wave 64x64
         case 2: return {32, 512, 16, 256};   // waves 1x4, wave 32x128
         case 3: return {128, 128, 32, 256};  // as 0 with 32-channel slabs (fewer barriers for k<=3)
+        case 5: return {32, 256, 16, 256};   // waves 1x4, wave 32x64: small footprint -> 4 workgroups per CU (HBM-bound layers)
         default: return {128, 64, 16, 256};  // waves 2x2, wave 64x32 (short sequences)
     }
 }
@@ -373,6 +375,7 @@ inline hipError_t launch_conv(int cfg, const ConvParams& p, hipStream_t s) {
         case 1: return launch_conv_t<1, 4, 2, 2, 16, 3>(p, grid, lds, s);
         case 2: return launch_conv_t<1, 4, 1, 4, 16, 2>(p, grid, lds, s);
         case 3: return launch_conv_t<2, 2, 2, 2, 32, 3>(p, grid, lds, s);
+        case 5: return launch_conv_t<1, 4, 1, 2, 16, 4>(p, grid, lds, s);
         default: return launch_conv_t<2, 2, 2, 1, 16, 3>(p, grid, lds, s);
     }
 }

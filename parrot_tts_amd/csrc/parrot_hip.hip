@@ -16,6 +16,7 @@
 #include "conv_bf16x6.h"
 #include "conv_mfma.h"
 #include "kernels_misc.h"
+#include "resblock_fused.h"
 
 using namespace parrot;
 
@@ -73,6 +74,27 @@ struct ProfRec {
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+static int prof_open(ProfRec& rec, int row, double flops, double bytes, hipStream_t s) {
+    if (g_prof_pool.empty()) {
+        HIP_TRY(hipEventCreate(&rec.a));
+        HIP_TRY(hipEventCreate(&rec.b));
+    } else {
+        rec.a = g_prof_pool.back().first;
+        rec.b = g_prof_pool.back().second;
+        g_prof_pool.pop_back();
+    }
+    rec.cfg = row;
+    rec.flops = flops;
+    rec.bytes = bytes;
+    HIP_TRY(hipEventRecord(rec.a, s));
+    return PARROT_OK;
+}
+static int prof_close(ProfRec& rec, hipStream_t s) {
+    HIP_TRY(hipEventRecord(rec.b, s));
+    g_prof.push_back(rec);
+    return PARROT_OK;
+}
 
 extern "C" int parrot_prof_begin(void) {
     for (auto& r : g_prof) g_prof_pool.push_back({r.a, r.b});
@@ -244,10 +266,10 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
         return w[((size_t)m * Cing + i) * k + j];
     };
     const int want_prec = (d->precision >= 0) ? d->precision : default_prec();
-    if (want_prec == 1 && c->Mg >= 64 && d->tile_cfg < 0) {
+    if (want_prec == 1 && c->Mg >= 64 && d->tile_cfg < 0) {  // at 32 rows the split kernel is slower than the exact one (measured)
         // split-bf16 plan: 16 channels per chunk, one MFMA k-step per tap; [m_tile][chunk*tap][piece][lane][8]
         c->prec = 1;
-        c->cfg = (c->Mg <= 64) ? 1 : 0;
+        c->cfg = (c->Mg <= 32) ? 2 : (c->Mg <= 64) ? 1 : 0;  // exact-kernel tile ids with the same block shapes
         const TileCfg t16 = tile_cfg(c->cfg);
         if (groups > 1 && c->Mg % t16.bm) return fail(PARROT_E_UNSUPPORTED, "conv_create: rows per group must be a multiple of the tile height");
         c->nchunks = (c->Cin + 15) / 16;
@@ -301,6 +323,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.pre = c->d.pre_act; p.pre_slope = c->d.pre_slope; p.act = c->d.act;
     p.epi = epi; p.div = div; p.u = c->u; p.u_inv16 = (65536 + c->u - 1) / c->u;
     p.groups = c->groups; p.Mg = c->Mg;
+    { static const int abl = [] { const char* e = getenv("PARROT_ABLATE"); return e ? atoi(e) : 0; }(); p.ablate = abl; }
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
     p.res_bstride = res_bstride > 0 ? res_bstride : p.y_bstride;
@@ -310,7 +333,13 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         p.wfrag = reinterpret_cast<const float*>(c->wfrag16);
         p.n_it = c->n_it16;
     }
-    const TileCfg t = tile_cfg(cfg);
+    TileCfg t = tile_cfg(cfg);
+    int variant16 = 0;
+    if (c->prec == 1) {  // bf16x6 tile variant: PARROT_BF16_WIDE=1 -> wave tile 64x128 (1 wave per SIMD)
+        static const int wide = [] { const char* e = getenv("PARROT_BF16_WIDE"); return e ? atoi(e) : 0; }();
+        variant16 = (cfg == 2) ? 4 : cfg + (wide ? 2 : 0);
+        bf16x6_tile(variant16, t.bm, t.bn);
+    }
     p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
     ProfRec rec{};
     if (g_prof_on) {
@@ -330,7 +359,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         rec.bytes = 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k);
         HIP_TRY(hipEventRecord(rec.a, s));
     }
-    HIP_TRY(c->prec == 1 ? launch_conv_bf16x6(cfg, p, s) : launch_conv(cfg, p, s));
+    HIP_TRY(c->prec == 1 ? launch_conv_bf16x6(variant16, p, s) : launch_conv(cfg, p, s));
     if (c->d.act == ACT_TANH) {  // dense (B, Cout, Tout) output assumed for the tanh layers (conv_post)
         const size_t n = (size_t)B * c->Cout * Tout;
         hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n);
@@ -477,6 +506,66 @@ static size_t voc_max_act(const parrot_voc* v, int B, int U) {
     return mx;
 }
 
+// One fused launch for ResBlock (stage i, kernel j) when the stage is narrow enough to live in LDS.
+// Off by default: correct and covered by the parity tests, but at B=64 it is not yet faster than the layer-by-layer
+// path (19.1 ms vs 16.9 ms for stages 3-4: C=16 runs on 32-row MFMAs and the halo costs 12-23 % extra work).
+static int g_fused = -1;
+static bool fused_enabled() {
+    if (g_fused < 0) {
+        const char* e = getenv("PARROT_FUSED");
+        g_fused = e ? (atoi(e) != 0) : 0;
+    }
+    return g_fused != 0;
+}
+extern "C" int parrot_set_fused_resblocks(int32_t on) {
+    g_fused = on ? 1 : 0;
+    return PARROT_OK;
+}
+static bool resblock_fusable(const parrot_voc* v, int stage, int j) {
+    const parrot_voc_cfg& c = v->cfg;
+    const int C = v->chan(stage), k = c.resblock_kernel_sizes[j];
+    if (!fused_enabled() || (C != 16 && C != 32) || !(k & 1)) return false;
+    const int per_rb = (c.resblock_type == 1 ? 2 : 1) * c.n_dil;
+    if (per_rb > RB_MAX_CONVS) return false;
+    int H = 0;
+    for (int m = 0; m < c.n_dil; ++m) {
+        const int reach = (k - 1) / 2 * c.resblock_dilation_sizes[j][m];
+        if (reach > RB_PAD) return false;
+        H += reach + (c.resblock_type == 1 ? (k - 1) / 2 : 0);
+    }
+    const int base = (stage * c.n_kernels + j) * per_rb;
+    for (int q = 0; q < per_rb; ++q)
+        if (v->rb[base + q]->prec != 0 || v->rb[base + q]->cfg != 2 || !v->rb[base + q]->wfrag) return false;
+    return resblock_window(C) - 2 * H >= 128;
+}
+static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, int B, int T, int epi, float div,
+                                 hipStream_t s) {
+    const parrot_voc_cfg& c = v->cfg;
+    const int per_rb = (c.resblock_type == 1 ? 2 : 1) * c.n_dil;
+    const int base = (stage * c.n_kernels + j) * per_rb;
+    ResblockParams p{};
+    p.x = x; p.y = y;
+    p.n_conv = per_rb; p.type = c.resblock_type;
+    p.k = c.resblock_kernel_sizes[j]; p.C = v->chan(stage); p.T = T; p.B = B;
+    p.epi = epi; p.div = div; p.slope = 0.1f;
+    int H = 0;
+    double macs = 0;
+    for (int q = 0; q < per_rb; ++q) {
+        const parrot_conv* pc = v->rb[base + q].get();
+        p.wfrag[q] = pc->wfrag; p.bias[q] = pc->bias; p.dil[q] = pc->dil;
+        H += (p.k - 1) / 2 * pc->dil;
+        macs += (double)B * p.C * p.C * p.k * T;
+    }
+    p.H = H;
+    p.TT = resblock_window(p.C) - 2 * H;
+    p.tiles = (T + p.TT - 1) / p.TT;
+    ProfRec rec{};
+    if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 2, 2.0 * macs, 4.0 * B * (double)p.C * T * (2 + (epi != EPI_STORE ? 1 : 0)), s));
+    HIP_TRY(launch_resblock_fused(p, s));
+    if (g_prof_on) TRY(prof_close(rec, s));
+    return PARROT_OK;
+}
+
 extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t U) {
     if (!v || B <= 0 || U <= 0) return 0;
     Arena a(nullptr, 0);
@@ -531,6 +620,10 @@ extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const in
             const float* r = X;
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
+            if (resblock_fusable(v, i, j)) {
+                TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, s));
+                continue;
+            }
             for (int m = 0; m < nd; ++m) {
                 const bool last = (m == nd - 1);
                 float* dst = last ? XS : ((m & 1) ? RB : RA);

@@ -22,6 +22,11 @@ def set_default_precision(prec: int) -> None:
     _lib.check(_lib.lib().parrot_set_default_precision(int(prec)))
 
 
+def set_fused_resblocks(on: bool) -> None:
+    """Route 16/32-channel ResBlocks through the fused LDS-resident kernel (csrc/resblock_fused.h)."""
+    _lib.check(_lib.lib().parrot_set_fused_resblocks(int(bool(on))))
+
+
 def stream_ptr(device=None) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 

@@ -53,6 +53,14 @@ def test_mfma_layout_probe():
     ops.selftest()
 
 
+@pytest.fixture(params=[False, True], ids=["layerwise", "fused_resblocks"])
+def fused(request):
+    """Low-channel ResBlocks either layer by layer or through the fused LDS-resident kernel."""
+    ops.set_fused_resblocks(request.param)
+    yield request.param
+    ops.set_fused_resblocks(False)
+
+
 @pytest.fixture(params=["f32", "bf16x6"])
 def prec(request):
     """Run a model-level test under both product-evaluation modes of the conv kernel (include/parrot_hip.h
@@ -207,7 +215,7 @@ VOC_GOLDENS = ["voc_small", "voc_small_singlespk", "voc_small_resblock2", "voc_f
 
 
 @pytest.mark.parametrize("name", VOC_GOLDENS)
-def test_vocoder_matches_reference_golden(golden_dir, name, prec):
+def test_vocoder_matches_reference_golden(golden_dir, name, prec, fused):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     m = json.loads(str(z["meta"]))
     h = _voc_cfg(name)
@@ -225,7 +233,7 @@ def test_vocoder_matches_reference_golden(golden_dir, name, prec):
             got = st[k[6:]].cpu().numpy()
             assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max()), k
     err = float(np.abs(y.cpu().numpy() - z["wav"]).max())
-    _report(test="vocoder_golden", name=name, precision=prec, wav_max_abs_err=err)
+    _report(test="vocoder_golden", name=name, precision=prec, fused=bool(fused), wav_max_abs_err=err)
     assert err <= (5e-4 if name.endswith("_hot") else 5e-5), f"waveform max-abs error {err}"
     # int16 PCM as the reference driver emits it: allow +-1 LSB where the fp32 error straddles an integer
     pcm = ops.wav_to_int16(y.squeeze(1)).cpu().numpy().astype(np.int32)
@@ -237,7 +245,7 @@ def test_vocoder_matches_reference_golden(golden_dir, name, prec):
     assert torch.equal(y, y2)
 
 
-def test_vocoder_matches_oracle_ragged_shapes(prec):
+def test_vocoder_matches_oracle_ragged_shapes(prec, fused):
     h = synth.small_voc_config()
     sd = synth.synth_voc_state_dict(h, seed=21, scale=1.0)
     g = _gen(h, sd)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tiles", type=str, default="-1,0,1,2,3")
     ap.add_argument("--layers", type=str, default="", help="comma separated layer names (default: all)")
+    ap.add_argument("--precision", type=int, default=-1, help="-1 library default, 0 exact fp32 MFMA, 1 split-bf16")
     a = ap.parse_args()
     dev = "cuda:0"
     want = set(a.layers.split(",")) if a.layers else None
@@ -41,7 +42,7 @@ def main():
         out = torch.empty(a.batch, cout, T, device=dev)
         for tile in [int(t) for t in a.tiles.split(",")]:
             try:
-                plan = ops.ConvPlan(w, b, dilation=dil, padding=dil * (k - 1) // 2, pre_act=1, pre_slope=0.1, tile_cfg=tile)
+                plan = ops.ConvPlan(w, b, dilation=dil, padding=dil * (k - 1) // 2, pre_act=1, pre_slope=0.1, tile_cfg=tile, precision=a.precision)
             except Exception as e:  # noqa: BLE001
                 print(json.dumps({"layer": name, "tile": tile, "error": str(e)}))
                 continue
