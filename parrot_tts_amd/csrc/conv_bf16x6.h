@@ -126,71 +126,75 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
         aptr[mt] = reinterpret_cast<const char*>(p.wfrag) + ((size_t)mtg * p.n_it) * 3072 + lane * 16;
     }
     const int rot = tn % p.nchunks;
-    s16x8 a_cur[WM][3], a_nxt[WM][3], b_cur[WN][3], b_nxt[WN][3];
+    // Two operand register sets in ping-pong: the step after the current one is always fetched straight into the
+    // OTHER set, so the loop has no register copies (48 v_mov per step cost as much issue time as the 24 MFMAs).
+    s16x8 a0[WM][3], b0[WN][3], a1[WM][3], b1[WN][3];
+    auto load_a = [&](s16x8 (&a)[WM][3], int step) {
 #pragma unroll
-    for (int mt = 0; mt < WM; ++mt)
+        for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) a_nxt[mt][pc] = *reinterpret_cast<const s16x8*>(aptr[mt] + (size_t)(rot * p.k) * 3072 + pc * 1024);
-
+            for (int pc = 0; pc < 3; ++pc) a[mt][pc] = *reinterpret_cast<const s16x8*>(aptr[mt] + (size_t)step * 3072 + pc * 1024);
+    };
+    const int colbase = wn * WN * 32 + l31;  // this lane's column at tap 0 (tile nt adds 32*nt: same swizzle bit)
+    auto load_b = [&](s16x8 (&bb)[WN][3], const char* __restrict__ xs, int tap) {
+        const int col = colbase + tap * p.dil;
+        const int off = col * 32 + ((half ^ ((col >> 3) & 1)) * 16);
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bb[nt][pc] = *reinterpret_cast<const s16x8*>(xs + pc * PIECE_BYTES + nt * 1024 + off);
+    };
+    auto mfmas = [&](const s16x8 (&a)[WM][3], const s16x8 (&bb)[WN][3]) {
+        // six terms, smallest first: x3w1, x1w3, x2w2, x2w1, x1w2, x1w1 (a = weight pieces, bb = activation pieces)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mt][PA[t]]),
+                                                                          __builtin_bit_cast(bf16x8, bb[nt][PB[t]]), acc[mt][nt], 0, 0, 0);
+    };
+    load_a(a0, rot * p.k);
     load_slab(rot);
     store_slab(0);
     __syncthreads();
 
-    const int colbase = wn * WN * 32 + l31;  // this lane's column at tap 0 (tile nt adds 32*nt: same swizzle bit)
-    auto b_off = [&](int col) { return col * 32 + ((half ^ ((col >> 3) & 1)) * 16); };
-    int cc = rot;  // current chunk
-    for (int c = 0; c < p.nchunks; ++c) {
-        const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
-        const bool more = (c + 1 < p.nchunks);
-        const int cn = (cc + 1 == p.nchunks) ? 0 : cc + 1;  // next chunk in rotated order
-        if (more && !(p.ablate & 4)) load_slab(cn);
-        {
-            const int o0 = b_off(colbase);
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) b_cur[nt][pc] = *reinterpret_cast<const s16x8*>(xs + pc * PIECE_BYTES + nt * 1024 + o0);
+    // Flat walk over all (chunk, tap) steps, two per iteration: even steps compute from set 0 while set 1 is being
+    // filled for the next step, odd steps the other way round.  Chunk boundaries (LDS buffer switch) can fall on
+    // either half; the step body handles them with uniform branches.
+    int cc = rot, cn = (rot + 1 == p.nchunks) ? 0 : rot + 1;  // current / next chunk in rotated order
+    int c = 0, j = 0;                                           // chunks done, tap within the chunk
+    const char* __restrict__ xs = smem_raw;
+    auto step = [&](s16x8 (&xa)[WM][3], s16x8 (&xb)[WN][3], s16x8 (&ya)[WM][3], s16x8 (&yb)[WN][3]) {
+        if (j == 0) {  // first tap of a chunk: its slab is in LDS (barrier passed); start fetching the next one
+            if (c + 1 < p.nchunks) load_slab(cn);
+            load_b(xb, xs, 0);
         }
-        for (int j = 0; j < p.k; ++j) {
-            // prefetch the next step's operands (after the chunk's last tap the B prefetch reads in-slab garbage
-            // that is discarded; after the very last step the A prefetch re-reads a valid step and is discarded)
-            const int step_n = (j + 1 < p.k) ? cc * p.k + j + 1 : cn * p.k;
-            const int on = b_off(colbase + (j + 1) * p.dil);
-#pragma unroll
-            for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    a_cur[mt][pc] = a_nxt[mt][pc];
-                    if (!(p.ablate & 1)) a_nxt[mt][pc] = *reinterpret_cast<const s16x8*>(aptr[mt] + (size_t)step_n * 3072 + pc * 1024);
-                }
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    if (!(p.ablate & 2)) b_nxt[nt][pc] = *reinterpret_cast<const s16x8*>(xs + pc * PIECE_BYTES + nt * 1024 + on);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(p.ablate & 8))
-#pragma unroll
-            for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt) {
-                    // smallest terms first
-                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-                    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                    for (int t = 0; t < 6; ++t)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[mt][PA[t]]),
-                                                                              __builtin_bit_cast(bf16x8, b_cur[nt][PB[t]]), acc[mt][nt], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) b_cur[nt][pc] = b_nxt[nt][pc];
+        const bool last_tap = (j + 1 == p.k);
+        load_a(ya, last_tap ? cn * p.k : cc * p.k + j + 1);  // after the very last step: a valid, unused re-read
+        if (!last_tap) load_b(yb, xs, j + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(xa, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (last_tap) {
+            if (c + 1 < p.nchunks) store_slab((c + 1) & 1);
+            __syncthreads();
+            ++c;
+            xs = smem_raw + (c & 1) * BUF_BYTES;
+            cc = cn;
+            cn = (cc + 1 == p.nchunks) ? 0 : cc + 1;
+            j = 0;
+        } else {
+            ++j;
         }
-        if (more && !(p.ablate & 4)) store_slab((c + 1) & 1);
-        __syncthreads();
-        cc = cn;
+    };
+    const int total = p.nchunks * p.k;
+    for (int st = 0; st < total; st += 2) {
+        step(a0, b0, a1, b1);
+        if (st + 1 < total) step(a1, b1, a0, b0);
     }
     conv_epilogue<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 }
@@ -211,25 +215,18 @@ inline hipError_t launch_conv_bf16x6_t(const ConvParams& p, dim3 grid, hipStream
     return hipGetLastError();
 }
 
-// bf16x6 tile variants: 0/1 = 128x128 / 64x256 (wave 64x64, 2 waves per SIMD);
-//                      2/3 = 128x256 / 64x512 (wave 64x128, 1 wave per SIMD: half the weight traffic per MFMA)
-//                      4   = 32x512 (waves 1x4, wave 32x128) for 32-row layers
+// bf16x6 tile variants: 0 = 128x128 (waves 2x2), 1 = 64x256 (waves 1x4); wave tile 64x64, 2 waves per SIMD.
+// (Measured and dropped: a 64x128 wave tile at 1 wave per SIMD, -8 %; a 32-row variant, slower than the exact kernel.)
 inline void bf16x6_tile(int variant, int& bm, int& bn) {
-    if (variant == 4) { bm = 32; bn = 512; return; }
     bm = (variant & 1) ? 64 : 128;
-    bn = (variant & 1) ? ((variant & 2) ? 512 : 256) : ((variant & 2) ? 256 : 128);
+    bn = (variant & 1) ? 256 : 128;
 }
 inline hipError_t launch_conv_bf16x6(int variant, const ConvParams& p, hipStream_t s) {
     int bm, bn;
     bf16x6_tile(variant, bm, bn);
     dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
-    switch (variant) {
-        case 1: return launch_conv_bf16x6_t<1, 4, 2, 2, 2>(p, grid, s);
-        case 2: return launch_conv_bf16x6_t<2, 2, 2, 4, 1>(p, grid, s);
-        case 3: return launch_conv_bf16x6_t<1, 4, 2, 4, 1>(p, grid, s);
-        case 4: return launch_conv_bf16x6_t<1, 4, 1, 4, 2>(p, grid, s);
-        default: return launch_conv_bf16x6_t<2, 2, 2, 2, 2>(p, grid, s);
-    }
+    if (variant & 1) return launch_conv_bf16x6_t<1, 4, 2, 2, 2>(p, grid, s);
+    return launch_conv_bf16x6_t<2, 2, 2, 2, 2>(p, grid, s);
 }
 
 }  // namespace parrot

@@ -269,7 +269,7 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
     if (want_prec == 1 && c->Mg >= 64 && d->tile_cfg < 0) {  // at 32 rows the split kernel is slower than the exact one (measured)
         // split-bf16 plan: 16 channels per chunk, one MFMA k-step per tap; [m_tile][chunk*tap][piece][lane][8]
         c->prec = 1;
-        c->cfg = (c->Mg <= 32) ? 2 : (c->Mg <= 64) ? 1 : 0;  // exact-kernel tile ids with the same block shapes
+        c->cfg = (c->Mg <= 64) ? 1 : 0;  // exact-kernel tile ids with the same block shapes
         const TileCfg t16 = tile_cfg(c->cfg);
         if (groups > 1 && c->Mg % t16.bm) return fail(PARROT_E_UNSUPPORTED, "conv_create: rows per group must be a multiple of the tile height");
         c->nchunks = (c->Cin + 15) / 16;
@@ -335,9 +335,8 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     }
     TileCfg t = tile_cfg(cfg);
     int variant16 = 0;
-    if (c->prec == 1) {  // bf16x6 tile variant: PARROT_BF16_WIDE=1 -> wave tile 64x128 (1 wave per SIMD)
-        static const int wide = [] { const char* e = getenv("PARROT_BF16_WIDE"); return e ? atoi(e) : 0; }();
-        variant16 = (cfg == 2) ? 4 : cfg + (wide ? 2 : 0);
+    if (c->prec == 1) {
+        variant16 = cfg;
         bf16x6_tile(variant16, t.bm, t.bn);
     }
     p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
