@@ -341,13 +341,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_mfma_kernel(
 struct TileCfg {
     int bm, bn, ci, threads;
 };
-constexpr int NUM_TILE_CFGS = 6;
+constexpr int NUM_TILE_CFGS = 7;
 __host__ inline TileCfg tile_cfg(int id) {
     switch (id) {
         case 0: return {128, 128, 16, 256};  // waves 2x2, wave 64x64
         case 1: return {64, 256, 16, 256};   // waves 1x4, wave 64x64
         case 2: return {32, 512, 16, 256};   // waves 1x4, wave 32x128
         case 3: return {128, 128, 32, 256};  // as 0 with 32-channel slabs (fewer barriers for k<=3)
+        case 6: return {16, 512, 16, 256};   // conv_mfma16.h: 16-row MFMA (v_mfma_f32_16x16x4_f32) for <= 16 output channels
         case 5: return {32, 256, 16, 256};   // waves 1x4, wave 32x64: small footprint -> 4 workgroups per CU (HBM-bound layers)
         default: return {128, 64, 16, 256};  // waves 2x2, wave 64x32 (short sequences)
     }

@@ -15,6 +15,7 @@
 #include "attn.h"
 #include "conv_bf16x6.h"
 #include "conv_mfma.h"
+#include "conv_mfma16.h"
 #include "kernels_misc.h"
 #include "resblock_fused.h"
 
@@ -176,6 +177,7 @@ static inline float bf16_to_f(uint16_t h) {
 }
 
 static int choose_cfg(int M, int k) {
+    if (M <= 16) return 6;
     if (M <= 32) return 2;
     if (M <= 64) return 1;
     return (k <= 3) ? 3 : 0;
@@ -224,6 +226,10 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
     if ((c->kk - 1) * c->dil > CONV_HALO) return fail(PARROT_E_UNSUPPORTED, "conv_create: (k-1)*dilation exceeds the LDS halo (64)");
     c->cfg = (d->tile_cfg >= 0) ? d->tile_cfg : choose_cfg(c->Mg, c->kk);
     if (c->cfg >= NUM_TILE_CFGS) return fail(PARROT_E_INVALID, "conv_create: tile_cfg out of range");
+    if (c->cfg == 6 && (d->transposed || groups != 1 || c->M > 16)) {
+        if (d->tile_cfg == 6) return fail(PARROT_E_UNSUPPORTED, "conv_create: the 16-row tile needs a plain conv with <= 16 output channels");
+        c->cfg = 2;
+    }
     const TileCfg t = tile_cfg(c->cfg);
     if (groups > 1 && c->Mg % t.bm) return fail(PARROT_E_UNSUPPORTED, "conv_create: rows per group must be a multiple of the tile height");
     const int CI = t.ci, QN = CI / 8;
@@ -233,6 +239,17 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
     const size_t nfl = ((size_t)mtiles * c->n_it + 1) * 256;  // +1 group: the kernel prefetches one past the end
     std::vector<float> pk(nfl, 0.f);
     const int k = d->k, Cing = c->Cin;
+    if (c->cfg == 6) {  // 16x16x4 fragments: [chunk][tap][lane][4]: row = lane&15, channel = 16*chunk + 4*e + (lane>>4)
+        c->n_it = c->nchunks * c->kk;
+        pk.assign(((size_t)c->n_it + 1) * 256, 0.f);
+        for (int ch = 0; ch < c->nchunks; ++ch)
+            for (int j = 0; j < c->kk; ++j)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = lane & 15, i = ch * 16 + 4 * e + (lane >> 4);
+                        if (m < c->M && i < Cing) pk[((size_t)ch * c->kk + j) * 256 + lane * 4 + e] = w[((size_t)m * Cing + i) * k + j];
+                    }
+    } else
     for (int mt = 0; mt < mtiles; ++mt)
         for (int ch = 0; ch < c->nchunks; ++ch)
             for (int j = 0; j < c->kk; ++j)
@@ -296,8 +313,8 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
         HIP_TRY(hipMalloc((void**)&c->wfrag16, n16 * sizeof(uint16_t)));
         HIP_TRY(hipMemcpy(c->wfrag16, pk16.data(), n16 * sizeof(uint16_t), hipMemcpyHostToDevice));
     } else {
-        HIP_TRY(hipMalloc((void**)&c->wfrag, nfl * sizeof(float)));
-        HIP_TRY(hipMemcpy(c->wfrag, pk.data(), nfl * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&c->wfrag, pk.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->wfrag, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (bias) {
         HIP_TRY(hipMalloc((void**)&c->bias, (size_t)d->c_out * sizeof(float)));
@@ -358,7 +375,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         rec.bytes = 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k);
         HIP_TRY(hipEventRecord(rec.a, s));
     }
-    HIP_TRY(c->prec == 1 ? launch_conv_bf16x6(variant16, p, s) : launch_conv(cfg, p, s));
+    HIP_TRY(c->prec == 1 ? launch_conv_bf16x6(variant16, p, s) : (cfg == 6 ? launch_conv_mfma16(p, s) : launch_conv(cfg, p, s)));
     if (c->d.act == ACT_TANH) {  // dense (B, Cout, Tout) output assumed for the tanh layers (conv_post)
         const size_t n = (size_t)B * c->Cout * Tout;
         hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n);

@@ -92,11 +92,13 @@ CONV_CASES = [
     (256, 1, 1, 1, 3, 23, False, False, 0),       # duration proj
     (20, 24, 5, 2, 2, 50, True, True, 0),         # odd channel counts (zero-padded chunks / rows)
     (3, 5, 3, 1, 1, 1, False, False, 0),          # T = 1
+    (16, 16, 7, 3, 3, 2000, True, True, 0),       # stage-4 shapes on the 16-row MFMA tile
+    (40, 9, 5, 1, 2, 300, False, True, 1),        # 16-row tile, 3 channel chunks, relu + late residual
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_conv1d_matches_torch(case, tile):
     cin, cout, k, dil, B, T, pre, res, act = case
     rng = _rng(cin * 131 + cout * 7 + k + dil + T + tile)
@@ -113,6 +115,10 @@ def test_conv1d_matches_torch(case, tile):
         y_ref = torch.tanh(y_ref)
     if res:
         y_ref = y_ref + r
+    if tile == 6 and cout > 16:
+        with pytest.raises(Exception):  # the 16-row MFMA tile only takes layers with <= 16 output channels
+            ops.ConvPlan(w, b, dilation=dil, padding=pad, tile_cfg=tile)
+        return
     plan = ops.ConvPlan(w, b, dilation=dil, padding=pad, pre_act=int(pre), pre_slope=0.1, act=act, tile_cfg=tile)
     y = plan(x.to(DEV), None if r is None else r.to(DEV)).cpu()
     assert y.shape == y_ref.shape
