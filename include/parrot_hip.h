@@ -73,9 +73,9 @@ typedef struct {
 #define PARROT_PREC_F32 0
 #define PARROT_PREC_BF16X6 1
 int parrot_set_default_precision(int32_t prec);
-/* Whole-ResBlock fused kernel for stages with 16 / 32 channels (csrc/resblock_fused.h); default off, or env
- * PARROT_FUSED=1.  Takes effect at the next forward. */
-int parrot_set_fused_resblocks(int32_t on);
+/* Whole-ResBlock fused kernels (csrc/resblock_fused.h): 0 off, 1 stages with 16 and 32 channels, 2 only 16-channel
+ * stages (default; env PARROT_FUSED overrides).  Takes effect at the next forward. */
+int parrot_set_fused_resblocks(int32_t mode);
 
 int parrot_conv_create(parrot_conv_t** out, const parrot_conv_desc* d, const float* w_host, const float* bias_host);
 void parrot_conv_destroy(parrot_conv_t*);

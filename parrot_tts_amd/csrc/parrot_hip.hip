@@ -523,24 +523,29 @@ static size_t voc_max_act(const parrot_voc* v, int B, int U) {
 }
 
 // One fused launch for ResBlock (stage i, kernel j) when the stage is narrow enough to live in LDS.
-// Off by default: correct and covered by the parity tests, but at B=64 it is not yet faster than the layer-by-layer
-// path (19.1 ms vs 16.9 ms for stages 3-4: C=16 runs on 32-row MFMAs and the halo costs 12-23 % extra work).
+// Fused whole-ResBlock kernels (resblock_fused.h): mode 0 off, 1 every eligible stage (16 and 32 channels), 2 only the
+// 16-channel stages.  Default 2: measured at B=64, the 16-channel kernel (16x16x4 MFMA, 1024-column windows) beats
+// the layer-by-layer path (5.3 vs 6.6 ms for stage 4) while the 32-channel one does not yet (10.5 vs 8.5 ms for
+// stage 3: 512-column windows pay 12-23 % halo recompute).  PARROT_FUSED / parrot_set_fused_resblocks override.
 static int g_fused = -1;
-static bool fused_enabled() {
+static int fused_mode() {
     if (g_fused < 0) {
         const char* e = getenv("PARROT_FUSED");
-        g_fused = e ? (atoi(e) != 0) : 0;
+        g_fused = e ? atoi(e) : 2;
+        if (g_fused < 0 || g_fused > 2) g_fused = 2;
     }
-    return g_fused != 0;
+    return g_fused;
 }
-extern "C" int parrot_set_fused_resblocks(int32_t on) {
-    g_fused = on ? 1 : 0;
+extern "C" int parrot_set_fused_resblocks(int32_t mode) {
+    if (mode < 0 || mode > 2) return fail(PARROT_E_INVALID, "set_fused_resblocks: mode must be 0, 1 or 2");
+    g_fused = mode;
     return PARROT_OK;
 }
 static bool resblock_fusable(const parrot_voc* v, int stage, int j) {
     const parrot_voc_cfg& c = v->cfg;
     const int C = v->chan(stage), k = c.resblock_kernel_sizes[j];
-    if (!fused_enabled() || (C != 16 && C != 32) || !(k & 1)) return false;
+    const int fm = fused_mode();
+    if (fm == 0 || !(C == 16 || (C == 32 && fm == 1)) || !(k & 1)) return false;
     const int per_rb = (c.resblock_type == 1 ? 2 : 1) * c.n_dil;
     if (per_rb > RB_MAX_CONVS) return false;
     int H = 0;
@@ -551,7 +556,7 @@ static bool resblock_fusable(const parrot_voc* v, int stage, int j) {
     }
     const int base = (stage * c.n_kernels + j) * per_rb;
     for (int q = 0; q < per_rb; ++q)
-        if (v->rb[base + q]->prec != 0 || v->rb[base + q]->cfg != 2 || !v->rb[base + q]->wfrag) return false;
+        if (v->rb[base + q]->prec != 0 || v->rb[base + q]->cfg != (C == 16 ? 6 : 2) || !v->rb[base + q]->wfrag) return false;
     return resblock_window(C) - 2 * H >= 128;
 }
 static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, int B, int T, int epi, float div,

@@ -181,6 +181,132 @@ __global__ __launch_bounds__(512, 1) void resblock_fused_kernel(const ResblockPa
     }
 }
 
+// ---- 16-channel variant on v_mfma_f32_16x16x4_f32 (no zero-padded MFMA rows; see conv_mfma16.h for the fragment
+// layouts).  Window 1024 columns, 8 waves x 8 tiles of 16; LDS row stride 16 (mod 32) dwords.
+constexpr int RB16_PAD = 40;
+__global__ __launch_bounds__(512, 1) void resblock_fused16_kernel(const ResblockParams p) {
+    constexpr int NT16 = 8;
+    constexpr int W0 = 8 * NT16 * 16;      // 1024
+    constexpr int RS = W0 + 2 * RB16_PAD;  // 1104 = 16 (mod 32)
+    static_assert(RS % 32 == 16, "row stride must be 16 mod 32 dwords");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // R[16][RS], S[16][RS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = lane >> 4;
+    const int l15 = lane & 15;
+    const int b = blockIdx.x / p.tiles;
+    const int tile = blockIdx.x - b * p.tiles;
+    const int t_base = tile * p.TT - p.H;
+    constexpr int C = 16;
+
+    float* R = smem;
+    float* S = smem + C * RS;
+    const float* __restrict__ xb = p.x + (size_t)b * C * p.T;
+    for (int idx = tid; idx < C * W0; idx += 512) {
+        const int row = idx / W0, c = idx - row * W0;
+        const int t = t_base + c;
+        const bool ok = t >= 0 && t < p.T;
+        const float v = xb[(size_t)row * p.T + (ok ? t : 0)];
+        R[row * RS + RB16_PAD + c] = ok ? v : 0.f;
+    }
+    for (int idx = tid; idx < C * 2 * RB16_PAD; idx += 512) {
+        const int row = idx / (2 * RB16_PAD), c = idx - row * (2 * RB16_PAD);
+        const int col = c < RB16_PAD ? c : W0 + c;
+        R[row * RS + col] = 0.f;
+        S[row * RS + col] = 0.f;
+    }
+    __syncthreads();
+
+    const int col0 = wave * (NT16 * 16) + l15;
+    auto conv_phase = [&](const float* src, float* dst, const float* res, const float* __restrict__ wfrag,
+                          const float* __restrict__ bias, int dil, bool lrelu_in, bool lrelu_out) {
+        f32x4 acc[NT16];
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][r] = 0.f;
+        const f32x4* __restrict__ ap = reinterpret_cast<const f32x4*>(wfrag) + lane;
+        const int center = (p.k - 1) / 2;
+        f32x4 a_nxt = ap[0], a_cur;
+        float bv_cur[4][NT16], bv_nxt[4][NT16];
+        const float* __restrict__ sb = src + kg * RS + RB16_PAD + col0 - center * dil;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT16; ++nt) bv_cur[e][nt] = sb[(4 * e) * RS + nt * 16];
+        for (int j = 0; j < p.k; ++j) {
+            const float* __restrict__ sn = sb + (j + 1) * dil;  // next tap (after the last: in-row, discarded)
+            a_cur = a_nxt;
+            a_nxt = ap[(size_t)(j + 1) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt) bv_nxt[e][nt] = sn[(4 * e) * RS + nt * 16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt) {
+                    const float v = bv_cur[e][nt];
+                    const float vs = v * p.slope;
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[e], (lrelu_in && v < 0.f) ? vs : v, acc[nt], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt) bv_cur[e][nt] = bv_nxt[e][nt];
+        }
+        // C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + r
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt) {
+            const int c = col0 + nt * 16;
+            const int t = t_base + c;
+            const bool tok = t >= 0 && t < p.T;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * kg + r;
+                float v = acc[nt][r] + bias[m];
+                if (res) v += res[m * RS + RB16_PAD + c];
+                const float vs = v * p.slope;
+                v = (lrelu_out && v < 0.f) ? vs : v;
+                dst[m * RS + RB16_PAD + c] = tok ? v : 0.f;
+            }
+        }
+    };
+
+    float* cur = R;
+    float* oth = S;
+    if (p.type == 1) {
+        for (int m = 0; m < p.n_conv; m += 2) {
+            conv_phase(cur, oth, nullptr, p.wfrag[m], p.bias[m], p.dil[m], true, true);
+            __syncthreads();
+            conv_phase(oth, cur, cur, p.wfrag[m + 1], p.bias[m + 1], p.dil[m + 1], false, false);
+            __syncthreads();
+        }
+    } else {
+        for (int m = 0; m < p.n_conv; ++m) {
+            conv_phase(cur, oth, cur, p.wfrag[m], p.bias[m], p.dil[m], true, false);
+            __syncthreads();
+            float* tmp = cur; cur = oth; oth = tmp;
+        }
+    }
+    float* __restrict__ yb = p.y + (size_t)b * C * p.T;
+    for (int idx = tid; idx < C * p.TT; idx += 512) {
+        const int row = idx / p.TT, c = idx - row * p.TT;
+        const int t = tile * p.TT + c;
+        if (t < p.T) {
+            float v = cur[row * RS + RB16_PAD + p.H + c];
+            const size_t o = (size_t)row * p.T + t;
+            if (p.epi == EPI_ADD) v = yb[o] + v;
+            else if (p.epi == EPI_ADD_DIV) v = (yb[o] + v) / p.div;
+            yb[o] = v;
+        }
+    }
+}
+
 template <int NTW>
 inline hipError_t launch_resblock_fused_t(const ResblockParams& p, hipStream_t s) {
     constexpr int RS = 8 * NTW * 32 + 2 * RB_PAD;
@@ -198,8 +324,21 @@ inline hipError_t launch_resblock_fused_t(const ResblockParams& p, hipStream_t s
 
 // window width for a channel count: the two fp32 buffers must fit 160 KiB of LDS
 inline int resblock_window(int C) { return C <= 16 ? 1024 : 512; }
+// C == 16: the plans are 16-row packs (tile config 6) and the 16x16x4 kernel runs; C == 32: 32-row packs (config 2)
 inline hipError_t launch_resblock_fused(const ResblockParams& p, hipStream_t s) {
-    return p.C <= 16 ? launch_resblock_fused_t<4>(p, s) : launch_resblock_fused_t<2>(p, s);
+    if (p.C == 16) {
+        const size_t lds = (size_t)2 * 16 * (1024 + 2 * RB16_PAD) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fused16_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(resblock_fused16_kernel, dim3(p.tiles * p.B), dim3(512), lds, s, p);
+        return hipGetLastError();
+    }
+    return launch_resblock_fused_t<2>(p, s);
 }
 
 }  // namespace parrot

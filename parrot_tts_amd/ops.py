@@ -22,9 +22,10 @@ def set_default_precision(prec: int) -> None:
     _lib.check(_lib.lib().parrot_set_default_precision(int(prec)))
 
 
-def set_fused_resblocks(on: bool) -> None:
-    """Route 16/32-channel ResBlocks through the fused LDS-resident kernel (csrc/resblock_fused.h)."""
-    _lib.check(_lib.lib().parrot_set_fused_resblocks(int(bool(on))))
+def set_fused_resblocks(mode: int) -> None:
+    """ResBlocks through the fused LDS-resident kernels (csrc/resblock_fused.h): 0 off, 1 for 16- and 32-channel
+    stages, 2 for 16-channel stages only (library default)."""
+    _lib.check(_lib.lib().parrot_set_fused_resblocks(int(mode)))
 
 
 def stream_ptr(device=None) -> C.c_void_p:

@@ -53,12 +53,12 @@ def test_mfma_layout_probe():
     ops.selftest()
 
 
-@pytest.fixture(params=[False, True], ids=["layerwise", "fused_resblocks"])
+@pytest.fixture(params=[0, 1, 2], ids=["layerwise", "fused_16_32", "fused_16"])
 def fused(request):
-    """Low-channel ResBlocks either layer by layer or through the fused LDS-resident kernel."""
+    """Low-channel ResBlocks layer by layer, or through the fused LDS-resident kernels (16+32 channels / 16 only)."""
     ops.set_fused_resblocks(request.param)
     yield request.param
-    ops.set_fused_resblocks(False)
+    ops.set_fused_resblocks(2)
 
 
 @pytest.fixture(params=["f32", "bf16x6"])
@@ -239,7 +239,7 @@ def test_vocoder_matches_reference_golden(golden_dir, name, prec, fused):
             got = st[k[6:]].cpu().numpy()
             assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max()), k
     err = float(np.abs(y.cpu().numpy() - z["wav"]).max())
-    _report(test="vocoder_golden", name=name, precision=prec, fused=bool(fused), wav_max_abs_err=err)
+    _report(test="vocoder_golden", name=name, precision=prec, fused=int(fused), wav_max_abs_err=err)
     assert err <= (5e-4 if name.endswith("_hot") else 5e-5), f"waveform max-abs error {err}"
     # int16 PCM as the reference driver emits it: allow +-1 LSB where the fp32 error straddles an integer
     pcm = ops.wav_to_int16(y.squeeze(1)).cpu().numpy().astype(np.int32)
