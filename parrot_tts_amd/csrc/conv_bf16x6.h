@@ -174,8 +174,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
             load_b(xb, xs, 0);
         }
         const bool last_tap = (j + 1 == p.k);
-        load_a(ya, last_tap ? cn * p.k : cc * p.k + j + 1);  // after the very last step: a valid, unused re-read
-        if (!last_tap) load_b(yb, xs, j + 1);
+        // both fetches are unconditional: a branch here makes hipcc merge wait-count states and stall every MFMA
+        // block on the reads issued just before it.  On a chunk's last tap the B fetch reads in-slab values that
+        // are discarded (step() reloads B after the barrier); after the very last step A re-reads a valid step.
+        load_a(ya, last_tap ? cn * p.k : cc * p.k + j + 1);
+        load_b(yb, xs, j + 1);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(xa, xb);
         __builtin_amdgcn_sched_barrier(0);

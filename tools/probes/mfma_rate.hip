@@ -54,7 +54,13 @@ void run(const char* name, int blocks_per_cu, s16x8* in, float* out) {
 
 int main() {
     s16x8* in; float* out;
-    hipMalloc(&in, 64 * 12 * sizeof(s16x8)); hipMemset(in, 0x3c, 64 * 12 * sizeof(s16x8));
+    hipMalloc(&in, 64 * 12 * sizeof(s16x8));
+    {   // random bf16 values in (-2, 2): realistic toggling -> realistic power / clock (zero or constant data overstates it)
+        unsigned short h[64 * 12 * 8];
+        unsigned st = 12345u;
+        for (auto& v : h) { st = st * 1664525u + 1013904223u; v = (unsigned short)(((st >> 16) & 0x807f) | (0x3f00 + ((st >> 9) & 0x80))); }
+        hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice);
+    }
     hipMalloc(&out, 256 * 3 * 256 * sizeof(float));
     for (int w = 1; w <= 3; ++w) {
         run<0>("bf16 32x32x16, 4 acc", w, in, out);
