@@ -137,9 +137,12 @@ int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parro
 void parrot_voc_destroy(parrot_voc_t*);
 size_t parrot_voc_workspace_bytes(const parrot_voc_t*, int32_t B, int32_t U);
 /* code (B,U) int64, spkr (B,1) int64 or NULL -> wav (B,1,U*prod(rates)) fp32 in (-1,1).
+ * unit_lens: optional (B) int32 device array of real units per row (ragged batch padded to U): every layer applies its
+ * zero padding at each row's own end, so row b[: unit_lens[b]*hop] equals the reference's B=1 run of that utterance
+ * (the reference never batches the vocoder, utils/vocoder/inference.py:149); samples beyond are unspecified.  NULL = all U.
  * stage_out: optional array of 2*n_stages+1 device pointers (conv_pre, ups_i, mrf_i ...) that
  * receive copies of the intermediate activations (tests only); NULL in production.            */
-int parrot_voc_forward(parrot_voc_t*, const int64_t* code, const int64_t* spkr, int32_t B, int32_t U,
+int parrot_voc_forward(parrot_voc_t*, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B, int32_t U,
                        float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream);
 int parrot_voc_check(parrot_voc_t*, void* stream);
 /* wav (n) fp32 -> int16 as `(x*32768).astype('int16')` does (utils/vocoder/inference.py:71-73) */

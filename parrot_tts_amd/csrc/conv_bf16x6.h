@@ -65,6 +65,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     const int tn = blockIdx.x - b * p.tiles_n;
     const int t0 = tn * BN;
     const int W = BN + (p.k - 1) * p.dil;
+    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;  // this row's true input length
     const int grp = (p.groups > 1) ? (blockIdx.y * BM) / p.Mg : 0;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride + (size_t)grp * p.Cin * p.Tin;
 
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
             const int oct = item / COLS;          // 0 / 1 (>= 2: idle slot)
             const int col = item - oct * COLS;
             const int tin = t0 - p.pad_left + col;
-            const bool colok = oct < 2 && col < W && tin >= 0 && tin < p.Tin;
+            const bool colok = oct < 2 && col < W && tin >= 0 && tin < Tlim;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int ch = c * 16 + oct * 8 + e;

@@ -63,6 +63,8 @@ struct ConvParams {
     int groups;          // grouped conv: Cin is PER GROUP, rows [g*Mg, (g+1)*Mg) read channels [g*Cin, (g+1)*Cin)
     int Mg;              // rows per group (multiple of the block's BM when groups > 1)
     int u_inv16;         // ceil(65536 / u)
+    const int32_t* row_len;  // optional per-batch-row true length (in base units); input positions >= row_len[b]*row_len_mul
+    int row_len_mul;         // read as zero: each row then sees its OWN sequence edge (ragged batches); null = Tin for all
     int ablate;          // debug only (PARROT_ABLATE): bit0 no A loads, bit1 no B reads, bit2 no slab staging, bit3 no MFMA, bit4 no residual preload, bit5 no epilogue
 };
 
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_mfma_kernel(
     const int tn = blockIdx.x - b * p.tiles_n;
     const int t0 = tn * BN;
     const int W = BN + (p.k - 1) * p.dil;  // live slab width (<= RS, checked on the host)
+    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;  // this row's true input length
     const int grp = (p.groups > 1) ? (blockIdx.y * BM) / p.Mg : 0;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride + (size_t)grp * p.Cin * p.Tin;
 
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_mfma_kernel(
             for (int i = 0; i < COLS_IT; ++i) {
                 const int col = lane + 64 * i;
                 const int tin = t0 - p.pad_left + col;
-                const bool ok = chok && col < W && tin >= 0 && tin < p.Tin;
+                const bool ok = chok && col < W && tin >= 0 && tin < Tlim;
                 float v = row[ok ? tin : 0];
                 v = ok ? v : 0.f;
                 const float vs = v * p.pre_slope;

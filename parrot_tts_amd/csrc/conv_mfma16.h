@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma16_kernel(const ConvParams
     const int tn = blockIdx.x - b * p.tiles_n;
     const int t0 = tn * BN;
     const int W = BN + (p.k - 1) * p.dil;
+    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride;
 
     float stage[ROWS_PW][COLS_IT];
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma16_kernel(const ConvParams
             for (int i = 0; i < COLS_IT; ++i) {
                 const int col = lane + 64 * i;
                 const int tin = t0 - p.pad_left + col;
-                const bool ok = chok && col < W && tin >= 0 && tin < p.Tin;
+                const bool ok = chok && col < W && tin >= 0 && tin < Tlim;
                 float v = row[ok ? tin : 0];
                 v = ok ? v : 0.f;
                 const float vs = v * p.pre_slope;

@@ -326,7 +326,8 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
 
 // x_bstride / y_bstride / res_bstride in elements; <= 0 means dense.
 static int conv_launch(const parrot_conv* c, const float* x, const float* res, float* y, int B, int Tin, int epi, float div,
-                       long x_bstride, long y_bstride, long res_bstride, hipStream_t s) {
+                       long x_bstride, long y_bstride, long res_bstride, hipStream_t s, const int32_t* row_len = nullptr,
+                       int row_len_mul = 1) {
     if (B <= 0 || Tin <= 0) return fail(PARROT_E_INVALID, "conv_run: empty batch or sequence");
     const int Tout = c->out_len(Tin);
     if (Tout <= 0) return fail(PARROT_E_INVALID, "conv_run: sequence shorter than the kernel");
@@ -340,6 +341,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.pre = c->d.pre_act; p.pre_slope = c->d.pre_slope; p.act = c->d.act;
     p.epi = epi; p.div = div; p.u = c->u; p.u_inv16 = (65536 + c->u - 1) / c->u;
     p.groups = c->groups; p.Mg = c->Mg;
+    p.row_len = row_len; p.row_len_mul = row_len_mul;
     { static const int abl = [] { const char* e = getenv("PARROT_ABLATE"); return e ? atoi(e) : 0; }(); p.ablate = abl; }
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
@@ -560,7 +562,7 @@ static bool resblock_fusable(const parrot_voc* v, int stage, int j) {
     return resblock_window(C) - 2 * H >= 128;
 }
 static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, int B, int T, int epi, float div,
-                                 hipStream_t s) {
+                                 hipStream_t s, const int32_t* row_len, int row_len_mul) {
     const parrot_voc_cfg& c = v->cfg;
     const int per_rb = (c.resblock_type == 1 ? 2 : 1) * c.n_dil;
     const int base = (stage * c.n_kernels + j) * per_rb;
@@ -569,6 +571,7 @@ static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const fl
     p.n_conv = per_rb; p.type = c.resblock_type;
     p.k = c.resblock_kernel_sizes[j]; p.C = v->chan(stage); p.T = T; p.B = B;
     p.epi = epi; p.div = div; p.slope = 0.1f;
+    p.row_len = row_len; p.row_len_mul = row_len_mul;
     int H = 0;
     double macs = 0;
     for (int q = 0; q < per_rb; ++q) {
@@ -596,8 +599,8 @@ extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, i
     return align_up(a.off, 256);
 }
 
-extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, int32_t B, int32_t U, float* wav_out,
-                                  float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
+                                  int32_t U, float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
     if (!v || !code || !wav_out || !ws) return fail(PARROT_E_INVALID, "voc_forward: null argument");
     if (B <= 0 || U <= 0) return fail(PARROT_E_INVALID, "voc_forward: empty batch");
     if (v->cfg.multispkr && !spkr) return fail(PARROT_E_INVALID, "voc_forward: multispkr model needs spkr ids");
@@ -621,7 +624,10 @@ extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const in
         return PARROT_OK;
     };
     int ia = 0;
-    TRY(conv_launch(v->conv_pre.get(), x0, nullptr, P[ia], B, U, EPI_STORE, 1.f, 0, 0, 0, s));
+    // unit_lens (optional): per-row number of real units; every layer then applies ITS zero padding at the row's own
+    // end (row_len * samples-per-unit so far), so a padded batch row equals the reference's B=1 run of that utterance
+    int mul = 1;
+    TRY(conv_launch(v->conv_pre.get(), x0, nullptr, P[ia], B, U, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
     TRY(snap(0, P[ia], (size_t)B * c.upsample_initial_channel * U));
     int T = U;
     const int nk = c.n_kernels, nd = c.n_dil;
@@ -633,8 +639,9 @@ extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const in
         float* T1 = P[(ia + 3) % 5];
         float* RA = P[(ia + 4) % 5];
         float* RB = A;  // the stage input is dead once ups[i] has consumed it
-        TRY(conv_launch(v->ups[i].get(), A, nullptr, X, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+        TRY(conv_launch(v->ups[i].get(), A, nullptr, X, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
         T = v->ups[i]->out_len(T);
+        mul *= c.upsample_rates[i];
         const size_t n_act = (size_t)B * v->chan(i) * T;
         TRY(snap(1 + 2 * i, X, n_act));
         for (int j = 0; j < nk; ++j) {
@@ -642,17 +649,17 @@ extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const in
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
             if (resblock_fusable(v, i, j)) {
-                TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, s));
+                TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, s, unit_lens, mul));
                 continue;
             }
             for (int m = 0; m < nd; ++m) {
                 const bool last = (m == nd - 1);
                 float* dst = last ? XS : ((m & 1) ? RB : RA);
                 if (c.resblock_type == 1) {
-                    TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
-                    TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, s));
+                    TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
+                    TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, s, unit_lens, mul));
                 } else {
-                    TRY(conv_launch(v->rb[base + m].get(), r, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, s));
+                    TRY(conv_launch(v->rb[base + m].get(), r, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, s, unit_lens, mul));
                 }
                 r = dst;
             }
@@ -660,7 +667,7 @@ extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const in
         TRY(snap(2 + 2 * i, XS, n_act));
         ia = (ia + 2) % 5;
     }
-    TRY(conv_launch(v->conv_post.get(), P[ia], nullptr, wav_out, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+    TRY(conv_launch(v->conv_post.get(), P[ia], nullptr, wav_out, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
     return PARROT_OK;
 }
 

@@ -39,6 +39,8 @@ struct ResblockParams {
     int epi;          // EPI_STORE / EPI_ADD / EPI_ADD_DIV on y
     float div;
     float slope;      // leaky-relu slope (0.1)
+    const int32_t* row_len;  // optional per-row true length in base units (x row_len_mul = samples at this stage)
+    int row_len_mul;
 };
 
 template <int NTW>
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(512, 1) void resblock_fused_kernel(const ResblockPa
     const int b = blockIdx.x / p.tiles;
     const int tile = blockIdx.x - b * p.tiles;
     const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
+    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;  // this row's true length
     const int C = p.C;
     const int nchunks = (C + 15) / 16;
 
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(512, 1) void resblock_fused_kernel(const ResblockPa
     for (int idx = tid; idx < C * W0; idx += 512) {
         const int row = idx / W0, c = idx - row * W0;
         const int t = t_base + c;
-        const bool ok = t >= 0 && t < p.T;
+        const bool ok = t >= 0 && t < Tlim;
         const float v = xb[(size_t)row * p.T + (ok ? t : 0)];
         R[row * RS + RB_PAD + c] = ok ? v : 0.f;
     }
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void resblock_fused_kernel(const ResblockPa
         for (int nt = 0; nt < NTW; ++nt) {
             const int c = col0 + nt * 32;
             const int t = t_base + c;
-            const bool tok = t >= 0 && t < p.T;
+            const bool tok = t >= 0 && t < Tlim;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(512, 1) void resblock_fused16_kernel(const Resblock
     const int b = blockIdx.x / p.tiles;
     const int tile = blockIdx.x - b * p.tiles;
     const int t_base = tile * p.TT - p.H;
+    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
     constexpr int C = 16;
 
     float* R = smem;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void resblock_fused16_kernel(const Resblock
     for (int idx = tid; idx < C * W0; idx += 512) {
         const int row = idx / W0, c = idx - row * W0;
         const int t = t_base + c;
-        const bool ok = t >= 0 && t < p.T;
+        const bool ok = t >= 0 && t < Tlim;
         const float v = xb[(size_t)row * p.T + (ok ? t : 0)];
         R[row * RS + RB16_PAD + c] = ok ? v : 0.f;
     }
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void resblock_fused16_kernel(const Resblock
         for (int nt = 0; nt < NT16; ++nt) {
             const int c = col0 + nt * 16;
             const int t = t_base + c;
-            const bool tok = t >= 0 && t < p.T;
+            const bool tok = t >= 0 && t < Tlim;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 4 * kg + r;

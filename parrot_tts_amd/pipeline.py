@@ -23,13 +23,15 @@ class SynthesisPipeline:
     def __call__(self, batch: Dict[str, torch.Tensor], spkr: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """batch: collated TTE batch (phones, src_mask, speaker).  ``spkr`` (B,1): vocoder speaker ids
         (defaults to the TTE speaker ids).  Returns wav (B,1,hop*L), n_samples (B,) = hop*emitted ids
-        per row (rows shorter than L emit len+1 ids, reference quirk Q2), ids, tgt_mask."""
+        per row (rows shorter than L emit len+1 ids, reference quirk Q2), ids, tgt_mask.  wav[b, :, n_samples[b]:] is
+        unspecified (padding)."""
         r = self.parrot.infer_dense(batch)
         ids = r["ids"]
         if spkr is None and self.generator.multispkr:
             spkr = batch["speaker"].reshape(-1, 1)
-        wav = self.generator(code=ids, spkr=spkr)
         hop = self.generator.upsample_factor
         L = ids.shape[1]
-        emitted = torch.clamp(r["lens"].to(torch.int64) + 1, max=L)
+        emitted = torch.clamp(r["lens"].to(torch.int64) + 1, max=L)  # ids per row as Parrot.infer returns them (Q2)
+        # each row is vocoded with its own sequence end, i.e. exactly as the reference would vocode that row's ids alone
+        wav = self.generator(code=ids, spkr=spkr, unit_lens=emitted)
         return {"wav": wav, "n_samples": emitted * hop, "ids": ids, "tgt_mask": r["tgt_mask"], "lens": r["lens"]}

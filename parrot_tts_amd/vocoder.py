@@ -223,7 +223,10 @@ class CodeGenerator(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, stages: Optional[dict] = None, **kwargs) -> torch.Tensor:
+    def forward(self, stages: Optional[dict] = None, unit_lens: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+        """``generator(code=..., spkr=...)`` as in the reference.  ``unit_lens`` (B,) int: real units per row of a padded
+        (ragged) batch -- every layer then zero-pads at each row's own end, so ``wav[b, :, :unit_lens[b]*hop]`` equals the
+        reference run of that utterance alone (the reference vocoder driver is B=1 only)."""
         extra = [k for k in kwargs if k not in ("code", "spkr", "f0")]
         if extra or kwargs.get("f0") is not None:
             raise NotImplementedError(f"extra conditioning features {extra or ['f0']} are not on the synthesis path")
@@ -242,6 +245,11 @@ class CodeGenerator(nn.Module):
             self._build(dev)
         code = code.contiguous()
         B, U = code.shape
+        lens32 = None
+        if unit_lens is not None:
+            lens32 = unit_lens.to(dev, torch.int32).contiguous()
+            if lens32.numel() != B:
+                raise ValueError("unit_lens must have one entry per batch row")
         lib = _lib.lib()
         key = (B, U)
         if key not in self._ws:
@@ -261,7 +269,7 @@ class CodeGenerator(nn.Module):
             stage_ptrs = (C.c_void_p * len(bufs))(*[C.c_void_p(b.data_ptr()) for b in bufs])
             stages.update(dict(zip(names, bufs)))
         with torch.cuda.device(dev):
-            _lib.check(lib.parrot_voc_forward(self._handle, dptr(code), dptr(spkr), B, U, dptr(wav), stage_ptrs, dptr(ws),
+            _lib.check(lib.parrot_voc_forward(self._handle, dptr(code), dptr(spkr), dptr(lens32), B, U, dptr(wav), stage_ptrs, dptr(ws),
                                               ws.numel(), stream_ptr(dev)))
         return wav
 

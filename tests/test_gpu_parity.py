@@ -390,3 +390,103 @@ def test_tte_error_behaviour(tmp_path):
         model.infer(bad)
     with pytest.raises(NotImplementedError):
         model(bad, inference=False)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json sizes: size-independent properties (the CPU oracle is too slow to referee B=64 x 256 units)
+# ----------------------------------------------------------------------------------------------
+def test_full_size_pipeline_properties(tmp_path):
+    """Batch 64 x 256 units, full-size models (BASELINE config 3 shapes): every row emits exactly 256 ids with
+    forced durations; rows are independent in the vocoder (row b of the batch == the same utterance alone, bit for
+    bit); the TTE row equals the same row inside a smaller batch of the SAME padded shape; a sampled row matches
+    the CPU oracle within the stated tolerance; output is finite and inside (-1, 1)."""
+    from parrot_tts_amd.pipeline import SynthesisPipeline
+    cfg, h = synth.default_tte_config(), synth.default_voc_config()
+    vocab, n_spk, B, S = 300, 10, 64, 64
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=42, forced_duration=4)
+    vsd = synth.synth_voc_state_dict(h, seed=1234, scale=1.0)
+    parrot = _parrot(cfg, vocab, n_spk, tsd, tmp_path)
+    gen = _gen(h, vsd)
+    batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=0)
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    out = SynthesisPipeline(parrot, gen)(gb)
+    ids, wav = out["ids"], out["wav"]
+    assert ids.shape == (B, 4 * S) and wav.shape == (B, 1, 4 * S * 320)
+    assert bool(out["tgt_mask"].all()) and out["lens"].tolist() == [4 * S] * B
+    assert int(out["n_samples"].min()) == 4 * S * 320
+    assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 1.0
+    # TTE: rows 8..15 as their own batch of the same padded shape -> identical ids (no cross-row op anywhere)
+    sub = {k: v[8:16].contiguous() for k, v in gb.items()}
+    assert torch.equal(parrot.infer_dense(sub)["ids"], ids[8:16])
+    # vocoder: row 5 alone == row 5 of the batch, bit for bit
+    spk = gb["speaker"].reshape(-1, 1)
+    assert torch.equal(gen(code=ids[5:6].contiguous(), spkr=spk[5:6].contiguous()), wav[5:6])
+    # one row against the CPU oracle (TTE ids exact where the margin allows; vocoder waveform within tolerance)
+    with torch.no_grad():
+        one = {k: v[3:4] for k, v in batch.items()}
+        ref = O.tte_forward(tsd, cfg, one)
+        top2 = torch.topk(ref["logits"], 2, dim=-1).values
+        decided = (top2[..., 0] - top2[..., 1]) > 1e-4
+        # B=1 and B=64 share the padded shape (S=64, L=256), so the reference gives the same row either way
+        assert torch.equal(ids[3:4].cpu()[decided], torch.argmax(ref["logits"], -1)[decided])
+        ref_wav = O.code_generator_forward(vsd, h, ids[3:4].cpu(), batch["speaker"][3:4].reshape(-1, 1))
+    err = float((wav[3:4].cpu() - ref_wav).abs().max())
+    _report(test="full_size_row_vs_oracle", wav_max_abs_err=err, decided_frac=float(decided.float().mean()))
+    assert err <= 5e-5
+
+
+def test_long_form_and_odd_lengths(tmp_path):
+    """BASELINE config 5 shape class: long sequences (no chunk streaming needed: the whole utterance fits the
+    workspace) and lengths that are not multiples of any tile size, against the CPU oracle (reduced-width models so
+    the oracle stays fast; the kernels and tilings are the same)."""
+    h = synth.small_voc_config()
+    vsd = synth.synth_voc_state_dict(h, seed=4)
+    gen = _gen(h, vsd)
+    for B, U in [(2, 1500), (1, 1237)]:
+        batch = synth.synth_voc_batch(B, U, h, seed=U)
+        with torch.no_grad():
+            ref = O.code_generator_forward(vsd, h, batch["code"], batch["spkr"])
+        y = gen(code=batch["code"].to(DEV), spkr=batch["spkr"].to(DEV)).cpu()
+        assert y.shape == (B, 1, U * 320)
+        assert float((y - ref).abs().max()) <= 5e-5
+    cfg = synth.small_tte_config()
+    cfg["transformer"]["max_len"] = 1700
+    tsd = synth.synth_tte_state_dict(cfg, 40, 2, seed=8, forced_duration=4)
+    model = _parrot(cfg, 40, 2, tsd, tmp_path)
+    tb = synth.synth_tte_batch(2, 375, 40, 2, seed=9, ragged=True)   # L = 1500 for the full row
+    with torch.no_grad():
+        ref = O.tte_forward(tsd, cfg, tb)
+        ref_rows = O.tte_infer(tsd, cfg, tb)
+    assert ref["logits"].shape[1] == 1500
+    got = model.infer({k: v.to(DEV) for k, v in tb.items()})
+    top2 = torch.topk(ref["logits"], 2, dim=-1).values
+    margin_ok = ((top2[..., 0] - top2[..., 1]) > 1e-4) | ~ref["tgt_mask"]
+    if bool(margin_ok.all()):
+        assert got == ref_rows
+    else:  # compare only decided positions
+        for g, r, ok, m in zip(got, ref_rows, margin_ok, ref["tgt_mask"]):
+            okm = ok[m].tolist()
+            assert len(g) == len(r) and all(a == b for a, b, o in zip(g, r, okm) if o)
+
+
+@pytest.mark.parametrize("cfg_name", ["small", "full"])
+def test_vocoder_ragged_batch_rows_equal_single_utterance_runs(cfg_name, prec, fused):
+    """A padded (ragged) batch with per-row unit counts: every row must equal the reference's own run of that utterance
+    ALONE (the reference vocoder driver is B=1), although the rows are padded with arbitrary codes."""
+    h = synth.small_voc_config() if cfg_name == "small" else synth.default_voc_config()
+    vsd = synth.synth_voc_state_dict(h, seed=31)
+    gen = _gen(h, vsd)
+    lens = [37, 11, 1, 24] if cfg_name == "small" else [21, 9]
+    U = max(lens)
+    batch = synth.synth_voc_batch(len(lens), U, h, seed=5)  # positions beyond lens[b] hold arbitrary (valid) codes
+    y = gen(code=batch["code"].to(DEV), spkr=batch["spkr"].to(DEV), unit_lens=torch.tensor(lens)).cpu()
+    hop = 320
+    for b, n in enumerate(lens):
+        with torch.no_grad():
+            ref = O.code_generator_forward(vsd, h, batch["code"][b:b + 1, :n], batch["spkr"][b:b + 1])
+        err = float((y[b:b + 1, :, : n * hop] - ref).abs().max())
+        assert err <= 5e-5, (b, n, err)
+    # without unit_lens the padded tail leaks into the last ~20 units of a short row (that is the point of the option)
+    y_plain = gen(code=batch["code"].to(DEV), spkr=batch["spkr"].to(DEV)).cpu()
+    n = lens[1]
+    assert float((y_plain[1, :, : n * hop] - y[1, :, : n * hop]).abs().max()) > 1e-3
