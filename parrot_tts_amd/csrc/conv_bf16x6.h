@@ -219,9 +219,11 @@ inline hipError_t launch_conv_bf16x6_t(const ConvParams& p, dim3 grid, hipStream
     return hipGetLastError();
 }
 
-// bf16x6 tile variants: 0 = 128x128 (waves 2x2), 1 = 64x256 (waves 1x4); wave tile 64x64, 2 waves per SIMD.
+// bf16x6 tile variants: 0 = 128x128 (waves 2x2), 1 = 64x256 (waves 1x4); wave tile 64x64, 2 waves per SIMD;
+//                      2 = 128x64 (waves 2x2, wave tile 64x32, 3 waves per SIMD) for 1x1 convs.
 // (Measured and dropped: a 64x128 wave tile at 1 wave per SIMD, -8 %; a 32-row variant, slower than the exact kernel.)
 inline void bf16x6_tile(int variant, int& bm, int& bn) {
+    if (variant == 2) { bm = 128; bn = 64; return; }   // wave tile 64x32, 3 waves per SIMD: 1x1 convs only
     bm = (variant & 1) ? 64 : 128;
     bn = (variant & 1) ? 256 : 128;
 }
@@ -229,6 +231,7 @@ inline hipError_t launch_conv_bf16x6(int variant, const ConvParams& p, hipStream
     int bm, bn;
     bf16x6_tile(variant, bm, bn);
     dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
+    if (variant == 2) return launch_conv_bf16x6_t<2, 2, 2, 1, 3>(p, grid, s);
     if (variant & 1) return launch_conv_bf16x6_t<1, 4, 2, 2, 2>(p, grid, s);
     return launch_conv_bf16x6_t<2, 2, 2, 2, 2>(p, grid, s);
 }

@@ -355,7 +355,9 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     TileCfg t = tile_cfg(cfg);
     int variant16 = 0;
     if (c->prec == 1) {
-        variant16 = cfg;
+        // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
+        // better (76 vs 61 TF on the qkv projection); every other layer is faster on the 64x64 wave tile
+        variant16 = (cfg == 0 && c->kk == 1) ? 2 : cfg;
         bf16x6_tile(variant16, t.bm, t.bn);
     }
     p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
@@ -372,7 +374,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         // algorithmic work of the layer (real taps only; DESIGN.md "roofline accounting")
         const double macs = (double)B * c->d.c_out * c->Cin * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         const double elems = (double)B * ((double)c->d.c_in * Tin + (double)c->Cout * Tout * (1 + (res ? 1 : 0) + (epi != EPI_STORE ? 1 : 0)));
-        rec.cfg = (c->prec == 1) ? NUM_TILE_CFGS + cfg : cfg;  // rows 5, 6 = the bf16x6 kernels
+        rec.cfg = (c->prec == 1) ? (variant16 == 2 ? NUM_TILE_CFGS + 3 : NUM_TILE_CFGS + cfg) : cfg;  // bf16x6 rows follow the exact ones
         rec.flops = 2.0 * macs;
         rec.bytes = 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k);
         HIP_TRY(hipEventRecord(rec.a, s));
