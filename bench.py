@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0
 SAMPLE_RATE = 16000             # reference utils/vocoder/config.json:32 (the metric's "22.05 kHz" does not match the reference)
 TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>", "conv_mfma_kernel<1,4,1,4,16,2>",
               "conv_mfma_kernel<2,2,2,2,32,3>", "conv_mfma_kernel<2,2,2,1,16,3>", "conv_mfma_kernel<1,4,1,2,16,4>",
-              "conv_mfma16_kernel<8,2>", "conv_bf16x6_kernel<2,2,2,2,2>", "conv_bf16x6_kernel<1,4,2,2,2>", "resblock_fused_kernel",
+              "conv_mfma16_kernel<8,2>", "conv_bf16x6_kernel<2,2,2,2,2>", "conv_bf16x6_kernel<1,4,2,2,2>", "resblock_fused16_kernel",
               "conv_bf16x6_kernel<2,2,2,1,3>"]
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the split scheme spends 6 bf16 MFMA FMAs per algorithmic fp32 FMA
 

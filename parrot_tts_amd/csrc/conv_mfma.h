@@ -65,7 +65,6 @@ struct ConvParams {
     int u_inv16;         // ceil(65536 / u)
     const int32_t* row_len;  // optional per-batch-row true length (in base units); input positions >= row_len[b]*row_len_mul
     int row_len_mul;         // read as zero: each row then sees its OWN sequence edge (ragged batches); null = Tin for all
-    int ablate;          // debug only (PARROT_ABLATE): bit0 no A loads, bit1 no B reads, bit2 no slab staging, bit3 no MFMA, bit4 no residual preload, bit5 no epilogue
 };
 
 // ACT_TANH (conv_post only) is applied by tanh_inplace_kernel right after the conv launch: inlining tanhf
@@ -89,7 +88,7 @@ __device__ __forceinline__ void conv_acc_init(const ConvParams& p, f32x16 (&acc)
     float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
     const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
     const bool plain = p.u == 1;
-    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE && !(p.ablate & 16);
+    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
     // pass 1: every residual element goes straight into its own accumulator register, so all WM*WN*16 loads are
     // in flight together (clamped addresses; masked lanes are never stored); pass 2 adds the bias.
 #pragma unroll

@@ -342,7 +342,6 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.epi = epi; p.div = div; p.u = c->u; p.u_inv16 = (65536 + c->u - 1) / c->u;
     p.groups = c->groups; p.Mg = c->Mg;
     p.row_len = row_len; p.row_len_mul = row_len_mul;
-    { static const int abl = [] { const char* e = getenv("PARROT_ABLATE"); return e ? atoi(e) : 0; }(); p.ablate = abl; }
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
     p.res_bstride = res_bstride > 0 ? res_bstride : p.y_bstride;
