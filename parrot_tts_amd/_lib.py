@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libparrot_hip.so")
+# PARROT_HIP_LIB: kernel-experiment builds of the same library (tools/); the default is the in-tree build
+LIB_PATH = os.environ.get("PARROT_HIP_LIB") or os.path.join(HERE, "libparrot_hip.so")
 
 MAX_STAGES, MAX_KERNELS, MAX_DIL = 8, 4, 4
 c_float_p = C.POINTER(C.c_float)

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libparrot_hip.so")
 SOURCES = ["parrot_hip.hip"]
-HEADERS = ["conv_mfma.h", "kernels_misc.h", "attn.h", os.path.join("..", "..", "include", "parrot_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "parrot_hip.h")]
 
 
 def _stale() -> bool:

@@ -18,6 +18,8 @@
 //     one global_load_dwordx4 per (m_tile, piece) per step, prefetched one step ahead.
 //   * accumulator init / epilogue are shared with the exact kernel (same 32x32 C/D layout).
 #pragma once
+#include <type_traits>
+
 #include "conv_mfma.h"
 
 namespace parrot {
@@ -32,6 +34,12 @@ __device__ __forceinline__ unsigned pk_bf16(float x0, float x1) {
     const f32x2 v = {x0, x1};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+// v_max_f32 without the canonicalising v_max(v, v) that fmaxf() puts in front of it for a freshly loaded operand
+__device__ __forceinline__ float max_nc(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // (x0, x1) -> three packed bf16 pairs with x ~= p0 + p1 + p2 (each subtraction is exact in fp32)
 __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
     p0 = pk_bf16(x0, x1);
@@ -41,7 +49,9 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& p0, unsi
     p2 = pk_bf16(s0, s1);
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW>
+// K > 0: the tap count is a compile-time constant and a whole chunk (K steps) is one straight-line block;
+// K == 0: any tap count, flat two-step walk with uniform branches at the chunk boundaries.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kernel(const ConvParams p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
     constexpr int BM = WAVES_M * WM * 32;
@@ -69,25 +79,36 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     const int grp = (p.groups > 1) ? (blockIdx.y * BM) / p.Mg : 0;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride + (size_t)grp * p.Cin * p.Tin;
 
+    // Slab fetch: one buffer descriptor over this batch row's (group's) input.  The per-lane offset is the time index
+    // (computed once per kernel; padding / past-the-row columns get an offset beyond num_records, for which the
+    // load returns 0 = the conv's zero padding), the channel goes into the wave-uniform scalar offset: no per-element
+    // address or predicate VALU work at all.  (COLS is a multiple of 64, so the channel octet of an item is
+    // wave-uniform; the host only selects this kernel when Cin % 16 == 0, 0 <= slope <= 1 and a row is < 2 GiB.)
+    static_assert(COLS % 64 == 0, "channel octet must be wave-uniform");
+    const size_t xaddr = reinterpret_cast<size_t>(xb);
+    const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((size_t)x_hi << 32) | x_lo), 0, 0x7fffffff, 0x00020000);
+    const int row_bytes = p.Tin * 4;
+    const float slope = (p.pre == PRE_LRELU) ? p.pre_slope : 1.f;
+    int voff[ITEMS], soct[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int item = tid + NT * i;
+        const int oct = item / COLS;
+        const int col = item - oct * COLS;
+        const int tin = t0 - p.pad_left + col;
+        voff[i] = (oct < 2 && tin >= 0 && tin < Tlim) ? tin * 4 : (int)0x80000000;  // (idle slots read out of range too)
+        soct[i] = __builtin_amdgcn_readfirstlane(min(oct, 1) * 8) * row_bytes;
+    }
     float stage[ITEMS][8];
     auto load_slab = [&](int c) {
+        const int cbase = c * 16 * row_bytes;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int item = tid + NT * i;
-            const int oct = item / COLS;          // 0 / 1 (>= 2: idle slot)
-            const int col = item - oct * COLS;
-            const int tin = t0 - p.pad_left + col;
-            const bool colok = oct < 2 && col < W && tin >= 0 && tin < Tlim;
+        for (int i = 0; i < ITEMS; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ch = c * 16 + oct * 8 + e;
-                const bool ok = colok && ch < p.Cin;
-                float v = xb[ok ? (size_t)ch * p.Tin + tin : 0];
-                v = ok ? v : 0.f;
-                const float vs = v * p.pre_slope;
-                stage[i][e] = (p.pre == PRE_LRELU && v < 0.f) ? vs : v;
-            }
-        }
+            for (int e = 0; e < 8; ++e)
+                stage[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff[i], cbase + soct[i] + e * row_bytes, 0));
     };
     auto store_slab = [&](int buf) {
         char* dst = smem_raw + buf * BUF_BYTES;
@@ -98,7 +119,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
             const int col = item - oct * COLS;
             unsigned q0[4], q1[4], q2[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split3_pk(stage[i][2 * e], stage[i][2 * e + 1], q0[e], q1[e], q2[e]);
+            for (int e = 0; e < 4; ++e) {
+                // leaky ReLU for 0 <= slope <= 1 (slope 1 = none) is max(v, slope * v); lrelu(0) = 0 keeps the padding
+                const float v0 = stage[i][2 * e], v1 = stage[i][2 * e + 1];
+                split3_pk(max_nc(v0, v0 * slope), max_nc(v1, v1 * slope), q0[e], q1[e], q2[e]);
+            }
             if (oct < 2) {
                 const uint4 v0 = {q0[0], q0[1], q0[2], q0[3]}, v1 = {q1[0], q1[1], q1[2], q1[3]}, v2 = {q2[0], q2[1], q2[2], q2[3]};
                 // the two channel octets of a column swap places on odd 8-column groups: with a 32 B column
@@ -120,21 +145,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     // Chunks are visited in an order rotated by the tile index: workgroups running side by side then stream
     // DIFFERENT weight lines at any moment instead of all hammering the same L2 channel in lockstep (the order
     // depends on the column tile only, so a batch row's result does not depend on the batch it sits in).
-    const char* __restrict__ aptr[WM];
+    // Weight stream addressing: one buffer descriptor (SGPR quad) for the whole packed stream, a constant per-lane byte
+    // offset (voffset) and a wave-uniform scalar offset per (m-tile, step) (soffset): each fetch is
+    // `buffer_load_dwordx4 v, v_lane, s[rsrc], s_off offen` -- no 64-bit VALU address math per step and no
+    // load-destination registers recycled as address temporaries.
+    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(p.wfrag));
+    const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<size_t>(p.wfrag) >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)w_hi << 32) | w_lo), 0, 0x7fffffff, 0x00020000);
+    int abase[WM];  // byte offset of each m-tile's stream (host guarantees the packed stream is < 2 GiB)
 #pragma unroll
-    for (int mt = 0; mt < WM; ++mt) {
-        const int mtg = blockIdx.y * (BM / 32) + wm * WM + mt;
-        aptr[mt] = reinterpret_cast<const char*>(p.wfrag) + ((size_t)mtg * p.n_it) * 3072 + lane * 16;
-    }
-    const int rot = tn % p.nchunks;
+    for (int mt = 0; mt < WM; ++mt)
+        abase[mt] = __builtin_amdgcn_readfirstlane((int)((blockIdx.y * (BM / 32) + wm * WM + mt) * p.n_it * 3072));
+    const unsigned lane16 = lane * 16;
+    // (workgroup b runs on XCD b % 8, so the rotation must vary with tn / 8 to differ between neighbours on one L2)
+    const int rot = __builtin_amdgcn_readfirstlane((tn + (tn >> 3)) % p.nchunks);  // (% runs on the VALU: pin the result to an SGPR)
     // Two operand register sets in ping-pong: the step after the current one is always fetched straight into the
     // OTHER set, so the loop has no register copies (48 v_mov per step cost as much issue time as the 24 MFMAs).
     s16x8 a0[WM][3], b0[WN][3], a1[WM][3], b1[WN][3];
     auto load_a = [&](s16x8 (&a)[WM][3], int step) {
+        const int soff = __builtin_amdgcn_readfirstlane(step) * 3072;
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) a[mt][pc] = *reinterpret_cast<const s16x8*>(aptr[mt] + (size_t)step * 3072 + pc * 1024);
+            for (int pc = 0; pc < 3; ++pc)
+                a[mt][pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, abase[mt] + soff, 0));
     };
     const int colbase = wn * WN * 32 + l31;  // this lane's column at tap 0 (tile nt adds 32*nt: same swizzle bit)
     auto load_b = [&](s16x8 (&bb)[WN][3], const char* __restrict__ xs, int tap) {
@@ -158,57 +193,160 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mt][PA[t]]),
                                                                           __builtin_bit_cast(bf16x8, bb[nt][PB[t]]), acc[mt][nt], 0, 0, 0);
     };
-    load_a(a0, rot * p.k);
-    load_slab(rot);
-    store_slab(0);
-    __syncthreads();
-
-    // Flat walk over all (chunk, tap) steps, two per iteration: even steps compute from set 0 while set 1 is being
-    // filled for the next step, odd steps the other way round.  Chunk boundaries (LDS buffer switch) can fall on
-    // either half; the step body handles them with uniform branches.
-    int cc = rot, cn = (rot + 1 == p.nchunks) ? 0 : rot + 1;  // current / next chunk in rotated order
-    int c = 0, j = 0;                                           // chunks done, tap within the chunk
-    const char* __restrict__ xs = smem_raw;
-    auto step = [&](s16x8 (&xa)[WM][3], s16x8 (&xb)[WN][3], s16x8 (&ya)[WM][3], s16x8 (&yb)[WN][3]) {
-        if (j == 0) {  // first tap of a chunk: its slab is in LDS (barrier passed); start fetching the next one
-            if (c + 1 < p.nchunks) load_slab(cn);
-            load_b(xb, xs, 0);
+    if constexpr (K > 0) {
+        // ---- static tap count: per chunk, one straight-line block of K steps --------------------------------
+        // Weights: two register sets in ping-pong, refilled IN PLACE two steps ahead: the six terms are ordered by
+        // weight piece (3rd, 2nd, 2nd, 1st, 1st, 1st), so piece 3 of the current set is dead after the first
+        // term, piece 2 after the third; each dead piece is immediately re-fetched for step + 2 (same set).  Every
+        // weight fetch then has 1.5-1.8 steps to land, and -- vmcnt retiring in order -- so do the slab loads issued
+        // at the top of the chunk: nothing waits on HBM latency inside a chunk.
+        s16x8 A[2][WM][3], Bv[2][WN][3];
+        constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
+        constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
+        auto load_a_piece = [&](s16x8 (&a)[WM][3], int pc, int soff) {
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+                a[mt][pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, abase[mt] + soff, 0));
+        };
+        auto next_chunk = [&](int q) { return (q + 1 == p.nchunks) ? 0 : q + 1; };
+        int cc = rot, cn = next_chunk(rot);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            load_a_piece(A[0], pc, cc * K * 3072);
+            load_a_piece(A[1], pc, (K > 1 ? cc * K + 1 : cn * K) * 3072);
         }
-        const bool last_tap = (j + 1 == p.k);
-        // both fetches are unconditional: a branch here makes hipcc merge wait-count states and stall every MFMA
-        // block on the reads issued just before it.  On a chunk's last tap the B fetch reads in-slab values that
-        // are discarded (step() reloads B after the barrier); after the very last step A re-reads a valid step.
-        load_a(ya, last_tap ? cn * p.k : cc * p.k + j + 1);
-        load_b(yb, xs, j + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(xa, xb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (last_tap) {
-            if (c + 1 < p.nchunks) store_slab((c + 1) & 1);
+        load_slab(rot);
+        store_slab(0);
+        __syncthreads();
+        auto chunk = [&](auto par, int c) {
+            constexpr int PAR = decltype(par)::value;
+            const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
+            const int cn2 = next_chunk(cn);
+            load_slab(cn);  // (after the last chunk: a harmless re-read, stored to the idle buffer)
+            load_b(Bv[PAR], xs, 0);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int cur = (PAR + j) & 1;
+                const int tq = (j + 2 < K) ? cc : (K == 1 ? cn2 : cn);  // step + 2 in the flat order
+                const int tj = (j + 2 < K) ? j + 2 : (K == 1 ? 0 : j + 2 - K);
+                const int soff = (tq * K + tj) * 3072;
+                if (j + 1 < K) load_b(Bv[cur ^ 1], xs, j + 1);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+#pragma unroll
+                    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < WN; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[cur][mt][PA[t]]),
+                                                                                  __builtin_bit_cast(bf16x8, Bv[cur][nt][PB[t]]), acc[mt][nt], 0, 0, 0);
+                    if (t == 0) load_a_piece(A[cur], 2, soff);
+                    if (t == 2) load_a_piece(A[cur], 1, soff);
+                    if (t == 5) load_a_piece(A[cur], 0, soff);
+                }
+            }
+            // Issue order of the block (hipcc would otherwise sink every prefetch down to its first use): one
+            // memory instruction in the shadow of each MFMA -- the re-fetch of a weight piece right after its last
+            // use, the next tap's activation fragments after that, and in the chunk's first step the slab loads.
+            constexpr int TM = WM * WN, NMF = 6 * TM;
+            constexpr int SLAB_SLOTS = NMF - (3 * TM - 1 + WM), SLAB_PER = (ITEMS * 8 + SLAB_SLOTS - 1) / SLAB_SLOTS;
+#pragma unroll
+            for (int i = 0; i < 3 * WN; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // tap 0 fragments
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                int ds_left = (j + 1 < K) ? 3 * WN : 0, slab_left = (j == 0) ? ITEMS * 8 : 0;
+#pragma unroll
+                for (int m = 0; m < NMF; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m >= TM - 1 && m < TM - 1 + WM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // piece 3
+                    if (m >= 3 * TM - 1 && m < 3 * TM - 1 + WM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // piece 2
+                    if (m >= TM - 1 + WM && ds_left > 0) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        --ds_left;
+                    }
+                    if (m >= 3 * TM - 1 + WM)
+#pragma unroll
+                        for (int q = 0; q < SLAB_PER; ++q)
+                            if (slab_left > 0) {
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                                --slab_left;
+                            }
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // piece 1
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            store_slab((c + 1) & 1);
             __syncthreads();
-            ++c;
-            xs = smem_raw + (c & 1) * BUF_BYTES;
             cc = cn;
-            cn = (cc + 1 == p.nchunks) ? 0 : cc + 1;
-            j = 0;
-        } else {
-            ++j;
+            cn = cn2;
+        };
+        for (int c = 0; c < p.nchunks; c += 2) {
+            chunk(std::integral_constant<int, 0>{}, c);
+            if (c + 1 < p.nchunks) chunk(std::integral_constant<int, (K & 1)>{}, c + 1);
         }
-    };
-    const int total = p.nchunks * p.k;
-    for (int st = 0; st < total; st += 2) {
-        step(a0, b0, a1, b1);
-        if (st + 1 < total) step(a1, b1, a0, b0);
+    } else {
+        load_a(a0, rot * p.k);
+        load_slab(rot);
+        store_slab(0);
+        __syncthreads();
+
+        // Flat walk over all (chunk, tap) steps, two per iteration: even steps compute from set 0 while set 1 is being
+        // filled for the next step, odd steps the other way round.  Chunk boundaries (LDS buffer switch) can fall on
+        // either half; the step body handles them with uniform branches.
+        int cc = rot, cn = (rot + 1 == p.nchunks) ? 0 : rot + 1;  // current / next chunk in rotated order
+        int c = 0, j = 0;                                           // chunks done, tap within the chunk
+        const char* __restrict__ xs = smem_raw;
+        auto step = [&](s16x8 (&xa)[WM][3], s16x8 (&xb)[WN][3], s16x8 (&ya)[WM][3], s16x8 (&yb)[WN][3]) {
+            if (j == 0) {  // first tap of a chunk: its slab is in LDS (barrier passed); start fetching the next one
+                if (c + 1 < p.nchunks) load_slab(cn);
+                load_b(xb, xs, 0);
+            }
+            const bool last_tap = (j + 1 == p.k);
+            // both fetches are unconditional: a branch here makes hipcc merge wait-count states and stall every MFMA
+            // block on the reads issued just before it.  On a chunk's last tap the B fetch reads in-slab values that
+            // are discarded (step() reloads B after the barrier); after the very last step A re-reads a valid step.
+            load_a(ya, last_tap ? cn * p.k : cc * p.k + j + 1);
+            load_b(yb, xs, j + 1);
+            mfmas(xa, xb);
+            // issue order inside the step: one prefetch instruction after every MFMA pair, so the loads' issue slots and
+            // address arithmetic sit in the matrix pipe's shadow instead of in front of the MFMA block
+    #pragma unroll
+            for (int g = 0; g < WM * 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read (weights)
+            }
+    #pragma unroll
+            for (int g = 0; g < WN * 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read (activations)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (last_tap) {
+                if (c + 1 < p.nchunks) store_slab((c + 1) & 1);
+                __syncthreads();
+                ++c;
+                xs = smem_raw + (c & 1) * BUF_BYTES;
+                cc = cn;
+                cn = (cc + 1 == p.nchunks) ? 0 : cc + 1;
+                j = 0;
+            } else {
+                ++j;
+            }
+        };
+        const int total = p.nchunks * p.k;
+        for (int st = 0; st < total; st += 2) {
+            step(a0, b0, a1, b1);
+            if (st + 1 < total) step(a1, b1, a0, b0);
+        }
     }
     conv_epilogue<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 }
 
-// bf16x6 tile table: index = the exact kernel's tile_cfg it stands in for (0: 128x128, 1: 64x256)
-template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K>
 inline hipError_t launch_conv_bf16x6_t(const ConvParams& p, dim3 grid, hipStream_t s) {
     constexpr int BN = WAVES_N * WN * 32;
     const size_t lds = (size_t)2 * 3 * (BN + CONV_HALO) * 32;
-    auto kern = conv_bf16x6_kernel<WAVES_M, WAVES_N, WM, WN, MINW>;
+    auto kern = conv_bf16x6_kernel<WAVES_M, WAVES_N, WM, WN, MINW, K>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -227,13 +365,25 @@ inline void bf16x6_tile(int variant, int& bm, int& bn) {
     bm = (variant & 1) ? 64 : 128;
     bn = (variant & 1) ? 256 : 128;
 }
+// the tap counts of the synthesis path get the straight-line kernel, anything else the generic one
+template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW>
+inline hipError_t launch_conv_bf16x6_k(const ConvParams& p, dim3 grid, hipStream_t s) {
+    switch (p.k) {
+        case 1: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 1>(p, grid, s);
+        case 3: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 3>(p, grid, s);
+        case 7: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 7>(p, grid, s);
+        case 9: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 9>(p, grid, s);
+        case 11: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 11>(p, grid, s);
+        default: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 0>(p, grid, s);
+    }
+}
 inline hipError_t launch_conv_bf16x6(int variant, const ConvParams& p, hipStream_t s) {
     int bm, bn;
     bf16x6_tile(variant, bm, bn);
     dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
-    if (variant == 2) return launch_conv_bf16x6_t<2, 2, 2, 1, 3>(p, grid, s);
-    if (variant & 1) return launch_conv_bf16x6_t<1, 4, 2, 2, 2>(p, grid, s);
-    return launch_conv_bf16x6_t<2, 2, 2, 2, 2>(p, grid, s);
+    if (variant == 2) return p.k == 1 ? launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1>(p, grid, s) : launch_conv_bf16x6_t<2, 2, 2, 1, 3, 0>(p, grid, s);
+    if (variant & 1) return launch_conv_bf16x6_k<1, 4, 2, 2, 2>(p, grid, s);
+    return launch_conv_bf16x6_k<2, 2, 2, 2, 2>(p, grid, s);
 }
 
 }  // namespace parrot

@@ -283,7 +283,10 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
         return w[((size_t)m * Cing + i) * k + j];
     };
     const int want_prec = (d->precision >= 0) ? d->precision : default_prec();
-    if (want_prec == 1 && c->Mg >= 64 && d->tile_cfg < 0) {  // at 32 rows the split kernel is slower than the exact one (measured)
+    // split kernel: at 32 rows it is slower than the exact one (measured); its slab fetch needs whole 16-channel chunks
+    // and evaluates the leaky ReLU as max(v, slope * v).  Everything else runs on the exact kernel (same results class).
+    const bool slope_ok = d->pre_act != PRE_LRELU || (d->pre_slope >= 0.f && d->pre_slope <= 1.f);
+    if (want_prec == 1 && c->Mg >= 64 && d->tile_cfg < 0 && c->Cin % 16 == 0 && slope_ok) {
         // split-bf16 plan: 16 channels per chunk, one MFMA k-step per tap; [m_tile][chunk*tap][piece][lane][8]
         c->prec = 1;
         c->cfg = (c->Mg <= 64) ? 1 : 0;  // exact-kernel tile ids with the same block shapes
@@ -293,6 +296,7 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
         c->n_it16 = c->nchunks * c->kk;
         const int mt16 = (c->M + t16.bm - 1) / t16.bm * (t16.bm / 32);
         const size_t n16 = ((size_t)mt16 * c->n_it16 + 1) * 1536;  // 3 pieces x 64 lanes x 8 bf16 per step (+1 pad step)
+        if (n16 * sizeof(uint16_t) >= ((size_t)1 << 31)) return fail(PARROT_E_UNSUPPORTED, "conv_create: packed weight stream larger than 2 GiB");
         std::vector<uint16_t> pk16(n16, 0);
         for (int mt = 0; mt < mt16; ++mt)
             for (int ch = 0; ch < c->nchunks; ++ch)
@@ -350,6 +354,8 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     if (c->prec == 1) {
         p.wfrag = reinterpret_cast<const float*>(c->wfrag16);
         p.n_it = c->n_it16;
+        // 32-bit byte offsets inside one batch row (buffer addressing of the slab fetch)
+        if ((double)c->Cin * Tin * 4.0 >= 2147483648.0) return fail(PARROT_E_UNSUPPORTED, "conv_run: batch row larger than 2 GiB");
     }
     TileCfg t = tile_cfg(cfg);
     int variant16 = 0;
