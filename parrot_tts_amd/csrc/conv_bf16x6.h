@@ -51,6 +51,15 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& p0, unsi
 
 // K > 0: the tap count is a compile-time constant and a whole chunk (K steps) is one straight-line block;
 // K == 0: any tap count, flat two-step walk with uniform branches at the chunk boundaries.
+// compile-time loop: f(integral_constant<0>) ... f(integral_constant<N-1>)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kernel(const ConvParams p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
@@ -92,28 +101,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     const int row_bytes = p.Tin * 4;
     const float slope = (p.pre == PRE_LRELU) ? p.pre_slope : 1.f;
     int voff[ITEMS], soct[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    static_for<ITEMS>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
         const int item = tid + NT * i;
         const int oct = item / COLS;
         const int col = item - oct * COLS;
         const int tin = t0 - p.pad_left + col;
         voff[i] = (oct < 2 && tin >= 0 && tin < Tlim) ? tin * 4 : (int)0x80000000;  // (idle slots read out of range too)
         soct[i] = __builtin_amdgcn_readfirstlane(min(oct, 1) * 8) * row_bytes;
-    }
+    });
     float stage[ITEMS][8];
-    auto load_slab = [&](int c) {
+    auto load_slab = [&](int c) __attribute__((always_inline)) {
         const int cbase = c * 16 * row_bytes;
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
+        static_for<ITEMS>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 stage[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff[i], cbase + soct[i] + e * row_bytes, 0));
+        });
     };
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int buf) __attribute__((always_inline)) {
         char* dst = smem_raw + buf * BUF_BYTES;
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
+        static_for<ITEMS>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const int item = tid + NT * i;
             const int oct = item / COLS;
             const int col = item - oct * COLS;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
                 *reinterpret_cast<uint4*>(dst + PIECE_BYTES + off) = v1;
                 *reinterpret_cast<uint4*>(dst + 2 * PIECE_BYTES + off) = v2;
             }
-        }
+        });
     };
 
     f32x16 acc[WM][WN];
@@ -218,18 +228,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
         load_slab(rot);
         store_slab(0);
         __syncthreads();
-        auto chunk = [&](auto par, int c) {
+        auto chunk = [&](auto par, int c) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par)::value;
             const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
             const int cn2 = next_chunk(cn);
+#ifndef EXP_NO_SLABLOAD
             load_slab(cn);  // (after the last chunk: a harmless re-read, stored to the idle buffer)
+#endif
             load_b(Bv[PAR], xs, 0);
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int cur = (PAR + j) & 1;
                 const int tq = (j + 2 < K) ? cc : (K == 1 ? cn2 : cn);  // step + 2 in the flat order
                 const int tj = (j + 2 < K) ? j + 2 : (K == 1 ? 0 : j + 2 - K);
+#ifdef EXP_A_CONST
+                const int soff = 0; (void)tq; (void)tj;
+#else
                 const int soff = (tq * K + tj) * 3072;
+#endif
                 if (j + 1 < K) load_b(Bv[cur ^ 1], xs, j + 1);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
@@ -275,8 +291,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
                 for (int i = 0; i < WM; ++i) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // piece 1
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifndef EXP_NO_STORE
             store_slab((c + 1) & 1);
+#endif
+#ifndef EXP_NO_BARRIER
             __syncthreads();
+#endif
             cc = cn;
             cn = cn2;
         };
@@ -358,10 +378,12 @@ inline hipError_t launch_conv_bf16x6_t(const ConvParams& p, dim3 grid, hipStream
 }
 
 // bf16x6 tile variants: 0 = 128x128 (waves 2x2), 1 = 64x256 (waves 1x4); wave tile 64x64, 2 waves per SIMD;
-//                      2 = 128x64 (waves 2x2, wave tile 64x32, 3 waves per SIMD) for 1x1 convs.
-// (Measured and dropped: a 64x128 wave tile at 1 wave per SIMD, -8 %; a 32-row variant, slower than the exact kernel.)
+//                      2 = 128x64 (waves 2x2, wave tile 64x32, 3 waves per SIMD) for 1x1 convs;
+//                      3 = 32x512 (waves 1x4, wave tile 32x128) for 32-channel layers.
+// (Measured and dropped: a 64x128 wave tile at 1 wave per SIMD, -8 %.)
 inline void bf16x6_tile(int variant, int& bm, int& bn) {
     if (variant == 2) { bm = 128; bn = 64; return; }   // wave tile 64x32, 3 waves per SIMD: 1x1 convs only
+    if (variant == 3) { bm = 32; bn = 512; return; }
     bm = (variant & 1) ? 64 : 128;
     bn = (variant & 1) ? 256 : 128;
 }
@@ -381,6 +403,7 @@ inline hipError_t launch_conv_bf16x6(int variant, const ConvParams& p, hipStream
     int bm, bn;
     bf16x6_tile(variant, bm, bn);
     dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
+    if (variant == 3) return launch_conv_bf16x6_k<1, 4, 1, 4, 2>(p, grid, s);
     if (variant == 2) return p.k == 1 ? launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1>(p, grid, s) : launch_conv_bf16x6_t<2, 2, 2, 1, 3, 0>(p, grid, s);
     if (variant & 1) return launch_conv_bf16x6_k<1, 4, 2, 2, 2>(p, grid, s);
     return launch_conv_bf16x6_k<2, 2, 2, 2, 2>(p, grid, s);

@@ -17,6 +17,7 @@
 #include "conv_mfma.h"
 #include "conv_mfma16.h"
 #include "kernels_misc.h"
+#include "resblock_bf16x6.h"
 #include "resblock_fused.h"
 
 using namespace parrot;
@@ -286,10 +287,10 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
     // split kernel: at 32 rows it is slower than the exact one (measured); its slab fetch needs whole 16-channel chunks
     // and evaluates the leaky ReLU as max(v, slope * v).  Everything else runs on the exact kernel (same results class).
     const bool slope_ok = d->pre_act != PRE_LRELU || (d->pre_slope >= 0.f && d->pre_slope <= 1.f);
-    if (want_prec == 1 && c->Mg >= 64 && d->tile_cfg < 0 && c->Cin % 16 == 0 && slope_ok) {
+    if (want_prec == 1 && c->Mg >= 32 && d->tile_cfg < 0 && c->Cin % 16 == 0 && slope_ok) {
         // split-bf16 plan: 16 channels per chunk, one MFMA k-step per tap; [m_tile][chunk*tap][piece][lane][8]
         c->prec = 1;
-        c->cfg = (c->Mg <= 64) ? 1 : 0;  // exact-kernel tile ids with the same block shapes
+        c->cfg = (c->Mg <= 32) ? 2 : (c->Mg <= 64) ? 1 : 0;  // exact-kernel tile ids with the same block shapes
         const TileCfg t16 = tile_cfg(c->cfg);
         if (groups > 1 && c->Mg % t16.bm) return fail(PARROT_E_UNSUPPORTED, "conv_create: rows per group must be a multiple of the tile height");
         c->nchunks = (c->Cin + 15) / 16;
@@ -362,7 +363,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     if (c->prec == 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
         // better (76 vs 61 TF on the qkv projection); every other layer is faster on the 64x64 wave tile
-        variant16 = (cfg == 0 && c->kk == 1) ? 2 : cfg;
+        variant16 = (cfg == 2) ? 3 : (cfg == 0 && c->kk == 1) ? 2 : cfg;
         bf16x6_tile(variant16, t.bm, t.bn);
     }
     p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
@@ -379,7 +380,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         // algorithmic work of the layer (real taps only; DESIGN.md "roofline accounting")
         const double macs = (double)B * c->d.c_out * c->Cin * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         const double elems = (double)B * ((double)c->d.c_in * Tin + (double)c->Cout * Tout * (1 + (res ? 1 : 0) + (epi != EPI_STORE ? 1 : 0)));
-        rec.cfg = (c->prec == 1) ? (variant16 == 2 ? NUM_TILE_CFGS + 3 : NUM_TILE_CFGS + cfg) : cfg;  // bf16x6 rows follow the exact ones
+        rec.cfg = (c->prec == 1) ? (variant16 >= 2 ? NUM_TILE_CFGS + 1 + variant16 : NUM_TILE_CFGS + cfg) : cfg;  // bf16x6 rows follow the exact ones
         rec.flops = 2.0 * macs;
         rec.bytes = 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k);
         HIP_TRY(hipEventRecord(rec.a, s));
@@ -444,8 +445,11 @@ struct parrot_voc {
     int* err = nullptr;
     std::unique_ptr<parrot_conv> conv_pre, conv_post;
     std::vector<std::unique_ptr<parrot_conv>> ups, rb;
+    std::vector<uint16_t*> rb_stream;  // per (stage, kernel): concatenated split-bf16 weight stream of the block (or null)
     int up_total = 1;
     ~parrot_voc() {
+        for (uint16_t* q : rb_stream)
+            if (q) (void)hipFree(q);
         if (dict) (void)hipFree(dict);
         if (spkr) (void)hipFree(spkr);
         if (err) (void)hipFree(err);
@@ -514,6 +518,28 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
             }
         }
     }
+    // 32-channel ResBlock1 blocks whose convs all run the split-bf16 scheme: one concatenated weight stream per block
+    // for the fused pair kernel (resblock_bf16x6.h); [conv][chunk * k + tap][piece][lane][8] + 2 pad steps
+    v->rb_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
+    for (int i = 0; i < cfg->n_stages; ++i)
+        for (int j = 0; j < cfg->n_kernels; ++j) {
+            const int rk = cfg->resblock_kernel_sizes[j];
+            if (cfg->resblock_type != 1 || v->chan(i) != 32 || !resblock_bf16x6_has_k(rk) || per_rb > RBS_MAX_CONVS) continue;
+            const int base = (i * cfg->n_kernels + j) * per_rb;
+            bool ok = true;
+            for (int q = 0; q < per_rb; ++q) {
+                const parrot_conv* pc = v->rb[base + q].get();
+                ok = ok && pc->prec == 1 && pc->wfrag16 && pc->nchunks == 2 && pc->n_it16 == 2 * rk && pc->M == 32;
+            }
+            if (!ok) continue;
+            const size_t step_b = 3072, conv_b = (size_t)2 * rk * step_b;
+            uint16_t* st = nullptr;
+            HIP_TRY(hipMalloc((void**)&st, per_rb * conv_b + 2 * step_b));
+            v->rb_stream[(size_t)i * cfg->n_kernels + j] = st;
+            for (int q = 0; q < per_rb; ++q)
+                HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + q * conv_b, v->rb[base + q]->wfrag16, conv_b, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + per_rb * conv_b, v->rb[base]->wfrag16, 2 * step_b, hipMemcpyDeviceToDevice));
+        }
     // final F.leaky_relu(x) uses the DEFAULT slope 0.01 (models.py:107, quirk Q5)
     TRY(make_conv(v->conv_post, C0 >> cfg->n_stages, 1, 7, 1, 3, 0, 1, PRE_LRELU, 0.01f, ACT_TANH, w->conv_post_w, w->conv_post_b));
     *out = v.release();
@@ -597,6 +623,58 @@ static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const fl
     return PARROT_OK;
 }
 
+// Split-bf16 fused pair kernel for a 32-channel ResBlock1 block: the pairs are grouped into launches whose total reach
+// stays <= hmax columns per side (a 384-column window keeps >= 84 % of its columns at hmax = 30); every launch but
+// the last stores its running residual to a scratch buffer.
+static int rbs_hmax() {
+    static const int h = [] { const char* e = getenv("PARROT_RBS_HMAX"); return e ? atoi(e) : 30; }();
+    return h;
+}
+static int resblock_split_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, float* tmp_a, float* tmp_b, int B, int T,
+                                 int epi, float div, hipStream_t s, const int32_t* row_len, int row_len_mul) {
+    const parrot_voc_cfg& c = v->cfg;
+    const int per_rb = 2 * c.n_dil, k = c.resblock_kernel_sizes[j];
+    const int base = (stage * c.n_kernels + j) * per_rb;
+    const uint16_t* stream = v->rb_stream[(size_t)stage * c.n_kernels + j];
+    const float* src = x;
+    int m0 = 0, n_launch = 0;
+    while (m0 < per_rb) {
+        int m1 = m0, H = 0;
+        while (m1 < per_rb) {
+            const int h2 = (k - 1) / 2 * (v->rb[base + m1]->dil + v->rb[base + m1 + 1]->dil);
+            if (m1 > m0 && H + h2 > rbs_hmax()) break;
+            H += h2;
+            m1 += 2;
+        }
+        const bool last = (m1 == per_rb);
+        ResblockSplitParams p{};
+        p.x = src;
+        p.y = last ? y : ((n_launch & 1) ? tmp_b : tmp_a);
+        p.wstream = stream + (size_t)m0 * 2 * k * 1536;
+        p.n_conv = m1 - m0;
+        for (int q = m0; q < m1; ++q) {
+            p.bias[q - m0] = v->rb[base + q]->bias;
+            p.dil[q - m0] = v->rb[base + q]->dil;
+        }
+        p.T = T; p.B = B; p.H = H;
+        p.TT = RBS_W - 2 * H;
+        if (p.TT < 32) return fail(PARROT_E_UNSUPPORTED, "resblock: receptive field too wide for the fused window");
+        p.tiles = (T + p.TT - 1) / p.TT;
+        p.epi = last ? epi : EPI_STORE;
+        p.div = div; p.slope = 0.1f;
+        p.row_len = row_len; p.row_len_mul = row_len_mul;
+        ProfRec rec{};
+        const double macs = (double)B * 32 * 32 * k * T * (m1 - m0);
+        if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 5, 2.0 * macs, 4.0 * B * 32.0 * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
+        HIP_TRY(launch_resblock_bf16x6(k, p, s));
+        if (g_prof_on) TRY(prof_close(rec, s));
+        src = p.y;
+        m0 = m1;
+        ++n_launch;
+    }
+    return PARROT_OK;
+}
+
 extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t U) {
     if (!v || B <= 0 || U <= 0) return 0;
     Arena a(nullptr, 0);
@@ -655,6 +733,10 @@ extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const in
             const float* r = X;
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
+            if (fused_mode() != 0 && v->rb_stream[(size_t)i * nk + j]) {
+                TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, s, unit_lens, mul));
+                continue;
+            }
             if (resblock_fusable(v, i, j)) {
                 TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, s, unit_lens, mul));
                 continue;

@@ -1,0 +1,286 @@
+// resblock_bf16x6.h -- HiFi-GAN ResBlock1 layer pairs (reference utils/vocoder/models.py:31-38) for the 32-channel
+// stage, fused per launch and evaluated with the split-bf16 scheme of conv_bf16x6.h (fp32 data, 6 bf16 MFMAs per
+// product, fp32 accumulate).
+//
+// Layer by layer the 32-channel stage is bandwidth bound (every conv streams (B, 32, T) in, the residual in and
+// the result out: 3 passes per conv, 18 convs).  Here a workgroup owns a window of W = 384 columns:
+//
+//   R  (running residual, fp32)  : REGISTERS, in the MFMA C/D layout -- wave w holds columns [96w, 96w+96), all 32
+//                                   channels (3 tiles of 32x32); the residual add is register + register.
+//   P  (conv operand, 3 x bf16)  : LDS, [piece][chunk][column][16 channels] = the B-fragment layout of
+//                                   conv_bf16x6.h; written straight from the accumulators (leaky ReLU, sequence
+//                                   mask, 3-way split), read with one ds_read_b128 per fragment.
+//
+//   per pair (dilation d):   P = split(lrelu(R));  h = conv_d(P) + b1;  P = split(lrelu(h));  R = conv_1(P) + b2 + R
+//
+// Each conv shrinks the valid region by its own reach, so after the launch's last conv the central W - 2H columns
+// are valid and are written out (columns outside are garbage that never feeds a valid one; fragment reads are
+// clamped to the window).  Positions outside the true sequence [0, T) are forced to zero after every conv: that IS
+// the reference's per-layer zero padding.  One operand buffer suffices (R never lives in LDS), at two barriers per
+// conv; 72 KiB of LDS and <= 256 VGPRs let two workgroups share a CU, so one's conversion phase overlaps the
+// other's MFMA phase.
+//
+// Weights: the conv plans' split streams ([step][piece][lane][8 bf16], step = chunk * K + tap), concatenated in conv
+// order into ONE stream per ResBlock, so the in-place two-steps-ahead weight prefetch (see conv_bf16x6.h) runs
+// straight across conv boundaries.
+#pragma once
+#include "conv_bf16x6.h"
+
+namespace parrot {
+
+constexpr int RBS_MAX_CONVS = 8;
+
+struct ResblockSplitParams {
+    const float* x;           // (B, 32, T) input of the first pair of this launch
+    float* y;                 // (B, 32, T) output (MRF accumulator or an intermediate buffer)
+    const uint16_t* wstream;  // this launch's first step in the ResBlock's concatenated weight stream (+2 pad steps at the end)
+    const float* bias[RBS_MAX_CONVS];
+    int dil[RBS_MAX_CONVS];
+    int n_conv;               // convs in this launch (even: whole pairs)
+    int T, B;
+    int H;                    // total reach of this launch's convs
+    int TT;                   // output columns per workgroup = W - 2H
+    int tiles;                // ceil(T / TT)
+    int epi;                  // EPI_STORE / EPI_ADD / EPI_ADD_DIV on y
+    float div;
+    float slope;
+    const int32_t* row_len;
+    int row_len_mul;
+};
+
+constexpr int RBS_W = 384;
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockSplitParams p) {
+    constexpr int C = 32, NCH = 2, NTW = 3, W = RBS_W, S = K * NCH;
+    constexpr int CH_BYTES = W * 32, PIECE_BYTES = NCH * CH_BYTES;  // [piece][chunk][col][16 ch] bf16
+    static_assert(4 * NTW * 32 == W, "4 waves x NTW tiles cover the window");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // 3 * PIECE_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int b = blockIdx.x / p.tiles;
+    const int tile = blockIdx.x - b * p.tiles;
+    const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
+    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
+    const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);  // window not fully inside the row
+
+    int col[NTW];   // this lane's window column per tile
+    bool tok[NTW];  // ... inside the sequence
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        col[nt] = wave * (NTW * 32) + nt * 32 + l31;
+        const int t = t_base + col[nt];
+        tok[nt] = t >= 0 && t < Tlim;
+    }
+
+    // ---- R <- x window, in the C/D layout: row m = (r & 3) + 8 (r >> 2) + 4 half, column = lane & 31 -------------
+    f32x16 R[NTW], acc[NTW];
+    {
+        const size_t xaddr = reinterpret_cast<size_t>(p.x + (size_t)b * C * p.T);
+        const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+        const __amdgpu_buffer_rsrc_t xrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)x_hi << 32) | x_lo), 0, 0x7fffffff, 0x00020000);
+        const int row_bytes = p.T * 4;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int voff = tok[nt] ? (t_base + col[nt]) * 4 + 4 * half * row_bytes : (int)0x80000000;  // out of range -> 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                R[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, ((r & 3) + 8 * (r >> 2)) * row_bytes, 0));
+        }
+    }
+
+    // ---- accumulator tile -> operand buffer: (leaky ReLU,) sequence mask, 3-way split, two 8-byte stores per
+    //      (tile, chunk, piece, row group): rows 8q+4g+{0..3} of this half are channels 16q + 8g + 4 half + {0..3}
+    auto write_p = [&](const f32x16 (&v)[NTW]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int swz = (col[nt] >> 3) & 1;
+#pragma unroll
+            for (int q = 0; q < NCH; ++q)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    unsigned q0[2], q1[2], q2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float v0 = v[nt][8 * q + 4 * g + 2 * e], v1 = v[nt][8 * q + 4 * g + 2 * e + 1];
+                        v0 = max_nc(v0, v0 * p.slope);
+                        v1 = max_nc(v1, v1 * p.slope);
+                        if (edge) {
+                            v0 = tok[nt] ? v0 : 0.f;
+                            v1 = tok[nt] ? v1 : 0.f;
+                        }
+                        split3_pk(v0, v1, q0[e], q1[e], q2[e]);
+                    }
+                    char* dst = smem_raw + q * CH_BYTES + col[nt] * 32 + ((g ^ swz) * 16) + 8 * half;
+                    *reinterpret_cast<uint2*>(dst) = uint2{q0[0], q0[1]};
+                    *reinterpret_cast<uint2*>(dst + PIECE_BYTES) = uint2{q1[0], q1[1]};
+                    *reinterpret_cast<uint2*>(dst + 2 * PIECE_BYTES) = uint2{q2[0], q2[1]};
+                }
+        }
+    };
+
+    // ---- weights: one buffer descriptor, per-lane constant offset, scalar step offset ----------------------------
+    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(p.wstream));
+    const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<size_t>(p.wstream) >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)w_hi << 32) | w_lo), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = lane * 16;
+    s16x8 A[2][3], Bv[2][NTW][3];
+    auto load_a_piece = [&](s16x8 (&a)[3], int pc, int gstep) __attribute__((always_inline)) {
+        a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, gstep * 3072, 0));
+    };
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+        load_a_piece(A[0], pc, 0);
+        load_a_piece(A[1], pc, 1);
+    }
+
+    if (edge) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) R[nt][r] = tok[nt] ? R[nt][r] : 0.f;  // (already 0 from the range check; keeps the invariant explicit)
+    }
+    write_p(R);
+    __syncthreads();
+
+    constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
+    constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
+    constexpr int center = (K - 1) / 2;
+    int gstep = 0;  // first step of the current conv in the stream
+    auto load_b = [&](s16x8 (&bb)[NTW][3], int ch, int shift) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int cc = min(max(col[nt] + shift, 0), W - 1);  // clamped: only garbage columns ever read a clamped one
+            const char* src = smem_raw + ch * CH_BYTES + cc * 32 + ((half ^ ((cc >> 3) & 1)) * 16);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bb[nt][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
+        }
+    };
+    // one conv out of P into acc (initialised by the caller); S = 2K straight-line steps
+    auto conv = [&](int dil) __attribute__((always_inline)) {
+        load_b(Bv[0], 0, -center * dil);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < S) load_b(Bv[cur ^ 1], (s + 1) / K, ((s + 1) % K - center) * dil);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[cur][PA[t]]),
+                                                                      __builtin_bit_cast(bf16x8, Bv[cur][nt][PB[t]]), acc[nt], 0, 0, 0);
+                if (t == 0) load_a_piece(A[cur], 2, gstep + s + 2);
+                if (t == 2) load_a_piece(A[cur], 1, gstep + s + 2);
+                if (t == 5) load_a_piece(A[cur], 0, gstep + s + 2);
+            }
+        }
+        // issue order: one memory instruction in the shadow of each MFMA (see conv_bf16x6.h)
+#pragma unroll
+        for (int i = 0; i < 3 * NTW; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            int ds_left = (s + 1 < S) ? 3 * NTW : 0;
+#pragma unroll
+            for (int m = 0; m < 6 * NTW; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m == NTW - 1 || m == 3 * NTW - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                else if (m >= NTW && ds_left > 0) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    --ds_left;
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gstep += S;
+    };
+    auto bias_rows = [&](const float* __restrict__ bias, float (&bv)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * half];
+    };
+
+    for (int m = 0; m < p.n_conv; m += 2) {
+        float bv[16];
+        // h = conv_d(P) + b1
+        bias_rows(p.bias[m], bv);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = bv[r];
+        conv(p.dil[m]);
+        __syncthreads();  // every wave is done reading P
+        write_p(acc);     // P = split(lrelu(h)), masked
+        __syncthreads();
+        // R = conv_1(P) + b2 + R
+        bias_rows(p.bias[m + 1], bv);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = bv[r] + R[nt][r];
+        conv(p.dil[m + 1]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) R[nt][r] = (!edge || tok[nt]) ? acc[nt][r] : 0.f;
+        if (m + 2 < p.n_conv) {
+            __syncthreads();
+            write_p(R);
+            __syncthreads();
+        }
+    }
+
+    // ---- write the central TT columns (registers -> global, 128-byte runs per row) ---------------------------------
+    float* __restrict__ yb = p.y + (size_t)b * C * p.T;
+    const bool has_acc = p.epi != EPI_STORE;
+    const bool do_div = p.epi == EPI_ADD_DIV;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int c = col[nt] - p.H;
+        const int t = tile * p.TT + c;
+        const bool ok = c >= 0 && c < p.TT && t < p.T;
+        float yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = 0.f;
+        if (has_acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yv[r] = yb[ok ? (size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = yv[r] + R[nt][r];
+            if (do_div) v = v / p.div;
+            if (ok) yb[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t] = v;
+        }
+    }
+}
+
+template <int K>
+inline hipError_t launch_resblock_bf16x6_t(const ResblockSplitParams& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)3 * 2 * RBS_W * 32;
+    auto kern = resblock_bf16x6_kernel<K>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+inline bool resblock_bf16x6_has_k(int k) { return k == 3 || k == 7 || k == 11; }
+inline hipError_t launch_resblock_bf16x6(int k, const ResblockSplitParams& p, hipStream_t s) {
+    switch (k) {
+        case 3: return launch_resblock_bf16x6_t<3>(p, s);
+        case 7: return launch_resblock_bf16x6_t<7>(p, s);
+        case 11: return launch_resblock_bf16x6_t<11>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace parrot

@@ -20,8 +20,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
     ap.add_argument("--csv")
+    ap.add_argument("--by-grid", action="store_true", help="one row per (kernel, grid): separates the layer shapes of one kernel")
     a = ap.parse_args()
     cur = sqlite3.connect(a.db).cursor()
+    if a.by_grid:
+        rows = cur.execute("select name, grid_x / workgroup_x, grid_y / workgroup_y, count(*), sum(duration), avg(duration) from kernels "
+                           "group by 1, 2, 3 order by 5 desc").fetchall()
+        total = sum(r[4] for r in rows) or 1
+        w = csv.writer(open(a.csv, "w", newline="") if a.csv else sys.stdout)
+        w.writerow(["kernel", "wg_x", "wg_y", "calls", "total_ms", "avg_us", "pct"])
+        for name, gx, gy, n, tot, avg in rows:
+            w.writerow([short(name), gx, gy, n, round(tot / 1e6, 4), round(avg / 1e3, 2), round(100.0 * tot / total, 2)])
+        return
     rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by 3 desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     pmc = {}
