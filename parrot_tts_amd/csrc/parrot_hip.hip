@@ -518,27 +518,57 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
             }
         }
     }
-    // 32-channel ResBlock1 blocks whose convs all run the split-bf16 scheme: one concatenated weight stream per block
-    // for the fused pair kernel (resblock_bf16x6.h); [conv][chunk * k + tap][piece][lane][8] + 2 pad steps
+    // ResBlock1 blocks of the 32- and 16-channel stages under the split-bf16 scheme: one concatenated weight stream per
+    // block for the fused pair kernels (resblock_bf16x6.h), [conv][step][piece][lane][8 bf16] + 2 pad steps.
+    //   32 channels: the conv plans' own streams (step = chunk * k + tap);
+    //   16 channels: packed here for the 16x16x32 MFMA (step = tap pair; lane = row l&15, channels 8(g&1).., tap 2*step + (g>>1)).
     v->rb_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
     for (int i = 0; i < cfg->n_stages; ++i)
         for (int j = 0; j < cfg->n_kernels; ++j) {
-            const int rk = cfg->resblock_kernel_sizes[j];
-            if (cfg->resblock_type != 1 || v->chan(i) != 32 || !resblock_bf16x6_has_k(rk) || per_rb > RBS_MAX_CONVS) continue;
+            const int rk = cfg->resblock_kernel_sizes[j], C = v->chan(i);
+            if (cfg->resblock_type != 1 || !(C == 32 || C == 16) || !resblock_bf16x6_has_k(rk) || per_rb > RBS_MAX_CONVS) continue;
             const int base = (i * cfg->n_kernels + j) * per_rb;
-            bool ok = true;
-            for (int q = 0; q < per_rb; ++q) {
-                const parrot_conv* pc = v->rb[base + q].get();
-                ok = ok && pc->prec == 1 && pc->wfrag16 && pc->nchunks == 2 && pc->n_it16 == 2 * rk && pc->M == 32;
+            const int steps = resblock_bf16x6_steps(C, rk);
+            const size_t step_b = 3072, conv_b = (size_t)steps * step_b;
+            if (C == 32) {
+                bool ok = true;
+                for (int q = 0; q < per_rb; ++q) {
+                    const parrot_conv* pc = v->rb[base + q].get();
+                    ok = ok && pc->prec == 1 && pc->wfrag16 && pc->nchunks == 2 && pc->n_it16 == steps && pc->M == 32;
+                }
+                if (!ok) continue;
+                uint16_t* st = nullptr;
+                HIP_TRY(hipMalloc((void**)&st, per_rb * conv_b + 2 * step_b));
+                v->rb_stream[(size_t)i * cfg->n_kernels + j] = st;
+                for (int q = 0; q < per_rb; ++q)
+                    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + q * conv_b, v->rb[base + q]->wfrag16, conv_b, hipMemcpyDeviceToDevice));
+                HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + per_rb * conv_b, v->rb[base]->wfrag16, 2 * step_b, hipMemcpyDeviceToDevice));
+            } else {
+                if (default_prec() != 1) continue;
+                std::vector<uint16_t> pk(((size_t)per_rb * steps + 2) * 1536, 0);
+                for (int q = 0; q < per_rb; ++q) {
+                    const float* wq = w->rb_w[base + q];  // (16, 16, rk)
+                    for (int st = 0; st < steps; ++st) {
+                        uint16_t* g = pk.data() + ((size_t)q * steps + st) * 1536;
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int row = lane & 15, ch = 8 * ((lane >> 4) & 1) + e, tap = 2 * st + (lane >> 5);
+                                const float val = tap < rk ? wq[((size_t)row * 16 + ch) * rk + tap] : 0.f;
+                                const uint16_t h1 = bf16_rn_host(val);
+                                const float r1 = val - bf16_to_f(h1);
+                                const uint16_t h2 = bf16_rn_host(r1);
+                                const uint16_t h3 = bf16_rn_host(r1 - bf16_to_f(h2));
+                                g[0 * 512 + lane * 8 + e] = h1;
+                                g[1 * 512 + lane * 8 + e] = h2;
+                                g[2 * 512 + lane * 8 + e] = h3;
+                            }
+                    }
+                }
+                uint16_t* st = nullptr;
+                HIP_TRY(hipMalloc((void**)&st, pk.size() * sizeof(uint16_t)));
+                v->rb_stream[(size_t)i * cfg->n_kernels + j] = st;
+                HIP_TRY(hipMemcpy(st, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             }
-            if (!ok) continue;
-            const size_t step_b = 3072, conv_b = (size_t)2 * rk * step_b;
-            uint16_t* st = nullptr;
-            HIP_TRY(hipMalloc((void**)&st, per_rb * conv_b + 2 * step_b));
-            v->rb_stream[(size_t)i * cfg->n_kernels + j] = st;
-            for (int q = 0; q < per_rb; ++q)
-                HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + q * conv_b, v->rb[base + q]->wfrag16, conv_b, hipMemcpyDeviceToDevice));
-            HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + per_rb * conv_b, v->rb[base]->wfrag16, 2 * step_b, hipMemcpyDeviceToDevice));
         }
     // final F.leaky_relu(x) uses the DEFAULT slope 0.01 (models.py:107, quirk Q5)
     TRY(make_conv(v->conv_post, C0 >> cfg->n_stages, 1, 7, 1, 3, 0, 1, PRE_LRELU, 0.01f, ACT_TANH, w->conv_post_w, w->conv_post_b));
@@ -633,8 +663,10 @@ static int rbs_hmax() {
 static int resblock_split_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, float* tmp_a, float* tmp_b, int B, int T,
                                  int epi, float div, hipStream_t s, const int32_t* row_len, int row_len_mul) {
     const parrot_voc_cfg& c = v->cfg;
-    const int per_rb = 2 * c.n_dil, k = c.resblock_kernel_sizes[j];
+    const int per_rb = 2 * c.n_dil, k = c.resblock_kernel_sizes[j], C = v->chan(stage);
     const int base = (stage * c.n_kernels + j) * per_rb;
+    const int W = resblock_bf16x6_window(C), steps = resblock_bf16x6_steps(C, k);
+    const int hmax = rbs_hmax() * (W / RBS_W);  // the same fraction of the window
     const uint16_t* stream = v->rb_stream[(size_t)stage * c.n_kernels + j];
     const float* src = x;
     int m0 = 0, n_launch = 0;
@@ -642,7 +674,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         int m1 = m0, H = 0;
         while (m1 < per_rb) {
             const int h2 = (k - 1) / 2 * (v->rb[base + m1]->dil + v->rb[base + m1 + 1]->dil);
-            if (m1 > m0 && H + h2 > rbs_hmax()) break;
+            if (m1 > m0 && H + h2 > hmax) break;
             H += h2;
             m1 += 2;
         }
@@ -650,23 +682,23 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         ResblockSplitParams p{};
         p.x = src;
         p.y = last ? y : ((n_launch & 1) ? tmp_b : tmp_a);
-        p.wstream = stream + (size_t)m0 * 2 * k * 1536;
+        p.wstream = stream + (size_t)m0 * steps * 1536;
         p.n_conv = m1 - m0;
         for (int q = m0; q < m1; ++q) {
             p.bias[q - m0] = v->rb[base + q]->bias;
             p.dil[q - m0] = v->rb[base + q]->dil;
         }
         p.T = T; p.B = B; p.H = H;
-        p.TT = RBS_W - 2 * H;
+        p.TT = W - 2 * H;
         if (p.TT < 32) return fail(PARROT_E_UNSUPPORTED, "resblock: receptive field too wide for the fused window");
         p.tiles = (T + p.TT - 1) / p.TT;
         p.epi = last ? epi : EPI_STORE;
         p.div = div; p.slope = 0.1f;
         p.row_len = row_len; p.row_len_mul = row_len_mul;
         ProfRec rec{};
-        const double macs = (double)B * 32 * 32 * k * T * (m1 - m0);
-        if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 5, 2.0 * macs, 4.0 * B * 32.0 * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
-        HIP_TRY(launch_resblock_bf16x6(k, p, s));
+        const double macs = (double)B * C * C * k * T * (m1 - m0);
+        if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
+        HIP_TRY(launch_resblock_bf16x6(C, k, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
         src = p.y;
         m0 = m1;

@@ -31,8 +31,8 @@ namespace parrot {
 constexpr int RBS_MAX_CONVS = 8;
 
 struct ResblockSplitParams {
-    const float* x;           // (B, 32, T) input of the first pair of this launch
-    float* y;                 // (B, 32, T) output (MRF accumulator or an intermediate buffer)
+    const float* x;           // (B, C, T) input of the first pair of this launch (C = 32 or 16: the kernel's)
+    float* y;                 // (B, C, T) output (MRF accumulator or an intermediate buffer)
     const uint16_t* wstream;  // this launch's first step in the ResBlock's concatenated weight stream (+2 pad steps at the end)
     const float* bias[RBS_MAX_CONVS];
     int dil[RBS_MAX_CONVS];
@@ -260,6 +260,208 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
     }
 }
 
+// ---- 16-channel variant on v_mfma_f32_16x16x32_bf16 -----------------------------------------------------------------
+// One MFMA k-step = 32 = 16 channels x TWO taps (an odd tap count is padded with one zero-weight tap), so a 16-channel
+// layer needs no zero-padded MFMA rows or k-slots beyond that.  Window 768 columns (72 KiB of LDS, two workgroups
+// per CU); wave w holds columns [192w, 192w+192) as 12 tiles of 16x16.
+//   A (weights)  : lane l = row l&15, k-group g = l>>4: channels 8(g&1)..+7 of tap 2*step + (g>>1); the host packs
+//                  [conv][step][piece][lane][8 bf16].
+//   B (operand)  : lane l = column l&15 (+ tap shift (g>>1)*dil), channels 8(g&1)..+7: one ds_read_b128 per piece.
+//   C/D          : column l&15, rows 4(l>>4) + r.
+// Per step the 12 tiles are walked in pairs (terms outer, the two tiles inner, so dependent MFMAs are one apart);
+// the next pair's fragments are fetched during the current pair's MFMAs.
+constexpr int RBS16_W = 768;
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const ResblockSplitParams p) {
+    constexpr int C = 16, NT = 12, W = RBS16_W, S = (K + 1) / 2, NP = NT / 2;
+    constexpr int PIECE_BYTES = W * 32;  // [piece][col][16 ch] bf16
+    static_assert(4 * NT * 16 == W, "4 waves x NT tiles cover the window");
+    static_assert(S % 2 == 0, "the two weight register sets alternate per step");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // 3 * PIECE_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g4 = lane >> 4;  // C/D row group; as an operand lane: channel octet g4 & 1, tap parity g4 >> 1
+    const int l15 = lane & 15;
+    const int b = blockIdx.x / p.tiles;
+    const int tile = blockIdx.x - b * p.tiles;
+    const int t_base = tile * p.TT - p.H;
+    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
+    const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);
+    const int col0 = wave * (NT * 16) + l15;  // this lane's window column in tile 0 (tile nt adds 16 nt)
+
+    f32x4 R[NT], acc[NT];
+    {
+        const size_t xaddr = reinterpret_cast<size_t>(p.x + (size_t)b * C * p.T);
+        const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+        const __amdgpu_buffer_rsrc_t xrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)x_hi << 32) | x_lo), 0, 0x7fffffff, 0x00020000);
+        const int row_bytes = p.T * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int t = t_base + col0 + nt * 16;
+            const int voff = (t >= 0 && t < Tlim) ? t * 4 + 4 * g4 * row_bytes : (int)0x80000000;  // out of range -> 0
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, r * row_bytes, 0));
+        }
+    }
+    auto write_p = [&](const f32x4 (&v)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = col0 + nt * 16;
+            const int t = t_base + c;
+            const bool tk = t >= 0 && t < Tlim;
+            unsigned q0[2], q1[2], q2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float v0 = v[nt][2 * e], v1 = v[nt][2 * e + 1];
+                v0 = max_nc(v0, v0 * p.slope);
+                v1 = max_nc(v1, v1 * p.slope);
+                if (edge) {
+                    v0 = tk ? v0 : 0.f;
+                    v1 = tk ? v1 : 0.f;
+                }
+                split3_pk(v0, v1, q0[e], q1[e], q2[e]);
+            }
+            char* dst = smem_raw + c * 32 + (((g4 >> 1) ^ ((c >> 3) & 1)) * 16) + 8 * (g4 & 1);
+            *reinterpret_cast<uint2*>(dst) = uint2{q0[0], q0[1]};
+            *reinterpret_cast<uint2*>(dst + PIECE_BYTES) = uint2{q1[0], q1[1]};
+            *reinterpret_cast<uint2*>(dst + 2 * PIECE_BYTES) = uint2{q2[0], q2[1]};
+        }
+    };
+
+    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(p.wstream));
+    const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<size_t>(p.wstream) >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)w_hi << 32) | w_lo), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = lane * 16;
+    s16x8 A[2][3], Bv[2][2][3];  // weights: two step sets; operands: two pair sets x two tiles x three pieces
+    auto load_a_piece = [&](s16x8 (&a)[3], int pc, int gstep) __attribute__((always_inline)) {
+        a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, gstep * 3072, 0));
+    };
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+        load_a_piece(A[0], pc, 0);
+        load_a_piece(A[1], pc, 1);
+    }
+    write_p(R);
+    __syncthreads();
+
+    constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
+    constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
+    constexpr int center = (K - 1) / 2;
+    int gstep = 0;
+    // fragments of tile pair pr at step s: column + (2s + tap parity - center) * dil, clamped to the window
+    auto load_b = [&](s16x8 (&bb)[2][3], int pr, int shift) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cc = min(max(col0 + (2 * pr + q) * 16 + shift, 0), W - 1);
+            const char* src = smem_raw + cc * 32 + (((g4 & 1) ^ ((cc >> 3) & 1)) * 16);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bb[q][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
+        }
+    };
+    auto conv = [&](int dil) __attribute__((always_inline)) {
+        const int tpd = (g4 >> 1) * dil - center * dil;  // this lane's tap-parity shift, centred
+        load_b(Bv[0], 0, tpd);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int cur = s & 1;
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                const int it = s * NP + pr;  // pair iterations alternate the operand sets
+                if (pr + 1 < NP) load_b(Bv[(it + 1) & 1], pr + 1, tpd + 2 * s * dil);
+                else if (s + 1 < S) load_b(Bv[(it + 1) & 1], 0, tpd + 2 * (s + 1) * dil);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[2 * pr + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[cur][PA[t]]),
+                                                                                  __builtin_bit_cast(bf16x8, Bv[it & 1][q][PB[t]]), acc[2 * pr + q], 0, 0, 0);
+                    if (pr == NP - 1) {  // last pair of the step: each weight piece is dead after its last term
+                        if (t == 0) load_a_piece(A[cur], 2, gstep + s + 2);
+                        if (t == 2) load_a_piece(A[cur], 1, gstep + s + 2);
+                        if (t == 5) load_a_piece(A[cur], 0, gstep + s + 2);
+                    }
+                }
+            }
+        }
+        // issue order: the next pair's six fragment reads in the shadow of the first six MFMAs of each pair
+#pragma unroll
+        for (int i = 0; i < 6; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                const bool more = (pr + 1 < NP) || (s + 1 < S);
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (more && m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (pr == NP - 1 && (m == 1 || m == 5 || m == 11)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        gstep += S;
+    };
+
+    for (int m = 0; m < p.n_conv; m += 2) {
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = p.bias[m][4 * g4 + r];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][r] = bv[r];
+        conv(p.dil[m]);
+        __syncthreads();
+        write_p(acc);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + 1][4 * g4 + r];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][r] = bv[r] + R[nt][r];
+        conv(p.dil[m + 1]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int t = t_base + col0 + nt * 16;
+            const bool tk = !edge || (t >= 0 && t < Tlim);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[nt][r] = tk ? acc[nt][r] : 0.f;
+        }
+        if (m + 2 < p.n_conv) {
+            __syncthreads();
+            write_p(R);
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ yb = p.y + (size_t)b * C * p.T;
+    const bool has_acc = p.epi != EPI_STORE;
+    const bool do_div = p.epi == EPI_ADD_DIV;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = col0 + nt * 16 - p.H;
+        const int t = tile * p.TT + c;
+        const bool ok = c >= 0 && c < p.TT && t < p.T;
+        float yv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = yb[ok ? (size_t)(4 * g4 + r) * p.T + t : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = yv[r] + R[nt][r];
+            if (do_div) v = v / p.div;
+            if (ok) yb[(size_t)(4 * g4 + r) * p.T + t] = v;
+        }
+    }
+}
+
 template <int K>
 inline hipError_t launch_resblock_bf16x6_t(const ResblockSplitParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)3 * 2 * RBS_W * 32;
@@ -273,8 +475,29 @@ inline hipError_t launch_resblock_bf16x6_t(const ResblockSplitParams& p, hipStre
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
     return hipGetLastError();
 }
+template <int K>
+inline hipError_t launch_resblock16_bf16x6_t(const ResblockSplitParams& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)3 * RBS16_W * 32;
+    auto kern = resblock16_bf16x6_kernel<K>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
 inline bool resblock_bf16x6_has_k(int k) { return k == 3 || k == 7 || k == 11; }
-inline hipError_t launch_resblock_bf16x6(int k, const ResblockSplitParams& p, hipStream_t s) {
+inline int resblock_bf16x6_window(int C) { return C == 16 ? RBS16_W : RBS_W; }
+inline int resblock_bf16x6_steps(int C, int k) { return C == 16 ? (k + 1) / 2 : 2 * k; }  // weight steps per conv
+inline hipError_t launch_resblock_bf16x6(int C, int k, const ResblockSplitParams& p, hipStream_t s) {
+    if (C == 16) switch (k) {
+            case 3: return launch_resblock16_bf16x6_t<3>(p, s);
+            case 7: return launch_resblock16_bf16x6_t<7>(p, s);
+            case 11: return launch_resblock16_bf16x6_t<11>(p, s);
+            default: return hipErrorInvalidValue;
+        }
     switch (k) {
         case 3: return launch_resblock_bf16x6_t<3>(p, s);
         case 7: return launch_resblock_bf16x6_t<7>(p, s);
