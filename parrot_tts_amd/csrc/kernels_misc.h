@@ -91,40 +91,71 @@ __global__ void add_channel_vec_kernel(float* __restrict__ x, const int64_t* __r
 __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ y, int C, int T,
                                                            float eps, int relu_in) {
+    // lane = time step, the four waves split the channels (c = wave, wave + 4, ...); for C <= 256 a thread's
+    // channel values stay in registers (one global read), wider layers re-read them per pass
     __shared__ float red[4][64];
+    constexpr int MAXV = 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane, b = blockIdx.y;
     const bool ok = t < T;
-    const float* xb = x + (size_t)b * C * T + t;
+    const float* xb = x + (size_t)b * C * T + (ok ? t : 0);
+    const bool in_regs = C <= 4 * MAXV;
+    float vals[MAXV];
     float s = 0.f;
-    if (ok)
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = wave + 4 * i;
+            float v = (c < C) ? xb[(size_t)c * T] : 0.f;
+            if (relu_in) v = v > 0.f ? v : 0.f;
+            vals[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) s += (wave + 4 * i < C) ? vals[i] : 0.f;
+    } else {
         for (int c = wave; c < C; c += 4) {
             float v = xb[(size_t)c * T];
             if (relu_in) v = v > 0.f ? v : 0.f;
             s += v;
         }
+    }
     red[wave][lane] = s;
     __syncthreads();
     const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
     __syncthreads();
     float q = 0.f;
-    if (ok)
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const float d = vals[i] - mean;
+            q += (wave + 4 * i < C) ? d * d : 0.f;
+        }
+    } else {
         for (int c = wave; c < C; c += 4) {
             float v = xb[(size_t)c * T];
             if (relu_in) v = v > 0.f ? v : 0.f;
             const float d = v - mean;
             q += d * d;
         }
+    }
     red[wave][lane] = q;
     __syncthreads();
     const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
     const float rstd = 1.0f / sqrtf(var + eps);
     if (ok) {
         float* yb = y + (size_t)b * C * T + t;
-        for (int c = wave; c < C; c += 4) {
-            float v = xb[(size_t)c * T];
-            if (relu_in) v = v > 0.f ? v : 0.f;
-            yb[(size_t)c * T] = (v - mean) * rstd * gamma[c] + beta[c];
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = wave + 4 * i;
+                if (c < C) yb[(size_t)c * T] = (vals[i] - mean) * rstd * gamma[c] + beta[c];
+            }
+        } else {
+            for (int c = wave; c < C; c += 4) {
+                float v = xb[(size_t)c * T];
+                if (relu_in) v = v > 0.f ? v : 0.f;
+                yb[(size_t)c * T] = (v - mean) * rstd * gamma[c] + beta[c];
+            }
         }
     }
 }
@@ -246,17 +277,42 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
 // argmax over channels of (B, V, L) logits -> ids (B, L); first maximal index wins (torch.argmax).
 // Optionally also writes logits transposed to the reference's (B, L, V) layout for tests.
 __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L) {
+    // lane = time step; the four waves scan a quarter of the vocabulary each, then the first maximum wins
+    // (strict > inside a range, lower range first on ties: torch.argmax's first-occurrence rule)
+    __shared__ float bv[4][64];
+    __shared__ int bix[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= L) return;
-    const float* lb = logits + (size_t)b * V * L + t;
-    float best = lb[0];
-    int bi = 0;
-    for (int v = 1; v < V; ++v) {
+    const int t = blockIdx.x * 64 + lane;
+    const bool ok = t < L;
+    const int per = (V + 3) / 4, v0 = wave * per, v1 = min(V, v0 + per);
+    const float* lb = logits + (size_t)b * V * L + (ok ? t : 0);
+    float best = -INFINITY;
+    int bi = v0 < V ? v0 : 0;
+    if (v0 < V) best = lb[(size_t)v0 * L];
+    int v = v0 + 1;
+    for (; v + 3 < v1; v += 4) {
+        const float x0 = lb[(size_t)v * L], x1 = lb[(size_t)(v + 1) * L], x2 = lb[(size_t)(v + 2) * L], x3 = lb[(size_t)(v + 3) * L];
+        if (x0 > best) { best = x0; bi = v; }
+        if (x1 > best) { best = x1; bi = v + 1; }
+        if (x2 > best) { best = x2; bi = v + 2; }
+        if (x3 > best) { best = x3; bi = v + 3; }
+    }
+    for (; v < v1; ++v) {
         const float x = lb[(size_t)v * L];
         if (x > best) { best = x; bi = v; }
     }
-    ids[(size_t)b * L + t] = bi;
+    bv[wave][lane] = best;
+    bix[wave][lane] = bi;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        float m = bv[0][lane];
+        int mi = bix[0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (bv[w][lane] > m) { m = bv[w][lane]; mi = bix[w][lane]; }
+        ids[(size_t)b * L + t] = mi;
+    }
 }
 
 // (B, C, T) -> (B, T, C) transpose (tests / optional logits export)

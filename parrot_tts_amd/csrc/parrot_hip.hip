@@ -519,7 +519,7 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
         }
     }
     // ResBlock1 blocks of the 32- and 16-channel stages under the split-bf16 scheme: one concatenated weight stream per
-    // block for the fused pair kernels (resblock_bf16x6.h), [conv][step][piece][lane][8 bf16] + 2 pad steps.
+    // block for the fused pair kernels (resblock_bf16x6.h), [conv][step][piece][lane][8 bf16] + padding for the prefetch past the end.
     //   32 channels: the conv plans' own streams (step = chunk * k + tap);
     //   16 channels: packed here for the 16x16x32 MFMA (step = tap pair; lane = row l&15, channels 8(g&1).., tap 2*step + (g>>1)).
     v->rb_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
@@ -537,12 +537,13 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
                     ok = ok && pc->prec == 1 && pc->wfrag16 && pc->nchunks == 2 && pc->n_it16 == steps && pc->M == 32;
                 }
                 if (!ok) continue;
+                // (the kernel's in-place prefetch after the last tap reads "the next conv's" tap 0 of both chunks: one
+                //  whole conv of padding keeps that inside the allocation)
                 uint16_t* st = nullptr;
-                HIP_TRY(hipMalloc((void**)&st, per_rb * conv_b + 2 * step_b));
+                HIP_TRY(hipMalloc((void**)&st, (per_rb + 1) * conv_b));
                 v->rb_stream[(size_t)i * cfg->n_kernels + j] = st;
-                for (int q = 0; q < per_rb; ++q)
-                    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + q * conv_b, v->rb[base + q]->wfrag16, conv_b, hipMemcpyDeviceToDevice));
-                HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + per_rb * conv_b, v->rb[base]->wfrag16, 2 * step_b, hipMemcpyDeviceToDevice));
+                for (int q = 0; q <= per_rb; ++q)
+                    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + q * conv_b, v->rb[base + (q < per_rb ? q : 0)]->wfrag16, conv_b, hipMemcpyDeviceToDevice));
             } else {
                 if (default_prec() != 1) continue;
                 std::vector<uint16_t> pk(((size_t)per_rb * steps + 2) * 1536, 0);
@@ -688,7 +689,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
             p.bias[q - m0] = v->rb[base + q]->bias;
             p.dil[q - m0] = v->rb[base + q]->dil;
         }
-        p.T = T; p.B = B; p.H = H;
+        p.T = T; p.B = B; p.H = H; p.k = k;
         p.TT = W - 2 * H;
         if (p.TT < 32) return fail(PARROT_E_UNSUPPORTED, "resblock: receptive field too wide for the fused window");
         p.tiles = (T + p.TT - 1) / p.TT;
@@ -698,7 +699,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         ProfRec rec{};
         const double macs = (double)B * C * C * k * T * (m1 - m0);
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
-        HIP_TRY(launch_resblock_bf16x6(C, k, p, s));
+        HIP_TRY(launch_resblock_bf16x6(C, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
         src = p.y;
         m0 = m1;
@@ -1033,7 +1034,7 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
     HIP_TRY(hipGetLastError());
     for (auto& Ly : t->dec) TRY(fft_block(t, Ly.get(), w, w.x, tgt_mask, B, L, s));
     TRY(conv_launch(t->head.get(), w.x, nullptr, w.logits, B, L, EPI_STORE, 1.f, 0, 0, 0, s));
-    hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, w.logits, ids, V, L);
+    hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, w.logits, ids, V, L);
     HIP_TRY(hipGetLastError());
     if (logits) {
         hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((L + 63) / 64, (V + 63) / 64, B), dim3(256), 0, s, w.logits, logits, V, L);

@@ -33,10 +33,11 @@ constexpr int RBS_MAX_CONVS = 8;
 struct ResblockSplitParams {
     const float* x;           // (B, C, T) input of the first pair of this launch (C = 32 or 16: the kernel's)
     float* y;                 // (B, C, T) output (MRF accumulator or an intermediate buffer)
-    const uint16_t* wstream;  // this launch's first step in the ResBlock's concatenated weight stream (+2 pad steps at the end)
+    const uint16_t* wstream;  // this launch's first step in the ResBlock's concatenated weight stream (padded past the end for the prefetch)
     const float* bias[RBS_MAX_CONVS];
     int dil[RBS_MAX_CONVS];
     int n_conv;               // convs in this launch (even: whole pairs)
+    int k;                    // taps of every conv of the block
     int T, B;
     int H;                    // total reach of this launch's convs
     int TT;                   // output columns per workgroup = W - 2H
@@ -50,9 +51,9 @@ struct ResblockSplitParams {
 
 constexpr int RBS_W = 384;
 
-template <int K>
 __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockSplitParams p) {
-    constexpr int C = 32, NCH = 2, NTW = 3, W = RBS_W, S = K * NCH;
+    constexpr int C = 32, NCH = 2, NTW = 3, W = RBS_W;
+    const int K = p.k;
     constexpr int CH_BYTES = W * 32, PIECE_BYTES = NCH * CH_BYTES;  // [piece][chunk][col][16 ch] bf16
     static_assert(4 * NTW * 32 == W, "4 waves x NTW tiles cover the window");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // 3 * PIECE_BYTES
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
     };
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
-        load_a_piece(A[0], pc, 0);
-        load_a_piece(A[1], pc, 1);
+        load_a_piece(A[0], pc, 0);  // (tap 0, chunk 0)
+        load_a_piece(A[1], pc, K);  // (tap 0, chunk 1)
     }
 
     if (edge) {
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
 
     constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
     constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
-    constexpr int center = (K - 1) / 2;
-    int gstep = 0;  // first step of the current conv in the stream
+    const int center = (K - 1) / 2;
+    int gbase = 0;  // first step of the current conv in the stream (step = chunk * K + tap)
     auto load_b = [&](s16x8 (&bb)[NTW][3], int ch, int shift) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -162,43 +163,49 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
             for (int pc = 0; pc < 3; ++pc) bb[nt][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
     };
-    // one conv out of P into acc (initialised by the caller); S = 2K straight-line steps
+    // one conv out of P into acc (initialised by the caller).  Tap loop; per tap two steps (channel chunk 0 with
+    // register sets 0, chunk 1 with sets 1).  On entry the weight sets hold this conv's (tap 0, chunk 0 / 1); each
+    // piece is re-fetched in place for the next tap (after the last tap: the next conv's tap 0) right after its last
+    // use, and the operand fragments of the next step are read during the current one.
+    // (A last, discarded fragment read follows the final step; the stream is padded by one conv for the prefetch.)
     auto conv = [&](int dil) __attribute__((always_inline)) {
         load_b(Bv[0], 0, -center * dil);
+        for (int j = 0; j < K; ++j) {
+            const int shift = (j - center) * dil;
+            const int n0 = (j + 1 < K) ? gbase + j + 1 : gbase + 2 * K;  // (tap + 1, chunk 0); chunk 1 is K steps further
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int cur = s & 1;
-            if (s + 1 < S) load_b(Bv[cur ^ 1], (s + 1) / K, ((s + 1) % K - center) * dil);
+            for (int ch = 0; ch < 2; ++ch) {
+                if (ch == 0) load_b(Bv[1], 1, shift);
+                else load_b(Bv[0], 0, shift + dil);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
+                for (int t = 0; t < 6; ++t) {
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[cur][PA[t]]),
-                                                                      __builtin_bit_cast(bf16x8, Bv[cur][nt][PB[t]]), acc[nt], 0, 0, 0);
-                if (t == 0) load_a_piece(A[cur], 2, gstep + s + 2);
-                if (t == 2) load_a_piece(A[cur], 1, gstep + s + 2);
-                if (t == 5) load_a_piece(A[cur], 0, gstep + s + 2);
-            }
-        }
-        // issue order: one memory instruction in the shadow of each MFMA (see conv_bf16x6.h)
-#pragma unroll
-        for (int i = 0; i < 3 * NTW; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            int ds_left = (s + 1 < S) ? 3 * NTW : 0;
-#pragma unroll
-            for (int m = 0; m < 6 * NTW; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (m == NTW - 1 || m == 3 * NTW - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                else if (m >= NTW && ds_left > 0) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    --ds_left;
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[ch][PA[t]]),
+                                                                          __builtin_bit_cast(bf16x8, Bv[ch][nt][PB[t]]), acc[nt], 0, 0, 0);
+                    if (t == 0) load_a_piece(A[ch], 2, n0 + ch * K);
+                    if (t == 2) load_a_piece(A[ch], 1, n0 + ch * K);
+                    if (t == 5) load_a_piece(A[ch], 0, n0 + ch * K);
                 }
             }
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            // issue order: one memory instruction in the shadow of each MFMA (see conv_bf16x6.h)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                int ds_left = 3 * NTW;
+#pragma unroll
+                for (int m = 0; m < 6 * NTW; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m == NTW - 1 || m == 3 * NTW - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    else if (ds_left > 0) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        --ds_left;
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        gstep += S;
+        gbase += 2 * K;
     };
     auto bias_rows = [&](const float* __restrict__ bias, float (&bv)[16]) __attribute__((always_inline)) {
 #pragma unroll
@@ -272,12 +279,11 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
 // the next pair's fragments are fetched during the current pair's MFMAs.
 constexpr int RBS16_W = 768;
 
-template <int K>
 __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const ResblockSplitParams p) {
-    constexpr int C = 16, NT = 12, W = RBS16_W, S = (K + 1) / 2, NP = NT / 2;
+    constexpr int C = 16, NT = 12, W = RBS16_W, NP = NT / 2;
+    const int K = p.k, S = (K + 1) / 2;  // tap pairs per conv (even: the host only takes k = 3, 7, 11)
     constexpr int PIECE_BYTES = W * 32;  // [piece][col][16 ch] bf16
     static_assert(4 * NT * 16 == W, "4 waves x NT tiles cover the window");
-    static_assert(S % 2 == 0, "the two weight register sets alternate per step");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // 3 * PIECE_BYTES
 
     const int tid = threadIdx.x;
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
 
     constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
     constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
-    constexpr int center = (K - 1) / 2;
+    const int center = (K - 1) / 2;
     int gstep = 0;
     // fragments of tile pair pr at step s: column + (2s + tap parity - center) * dil, clamped to the window
     auto load_b = [&](s16x8 (&bb)[2][3], int pr, int shift) __attribute__((always_inline)) {
@@ -363,47 +369,46 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
             for (int pc = 0; pc < 3; ++pc) bb[q][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
     };
+    // one conv: loop over step pairs (weight set 0 / 1), six tile pairs per step alternating the operand sets
     auto conv = [&](int dil) __attribute__((always_inline)) {
         const int tpd = (g4 >> 1) * dil - center * dil;  // this lane's tap-parity shift, centred
         load_b(Bv[0], 0, tpd);
+        for (int s2 = 0; s2 < S; s2 += 2) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int cur = s & 1;
+            for (int sub = 0; sub < 2; ++sub) {
+                const int s = s2 + sub;
 #pragma unroll
-            for (int pr = 0; pr < NP; ++pr) {
-                const int it = s * NP + pr;  // pair iterations alternate the operand sets
-                if (pr + 1 < NP) load_b(Bv[(it + 1) & 1], pr + 1, tpd + 2 * s * dil);
-                else if (s + 1 < S) load_b(Bv[(it + 1) & 1], 0, tpd + 2 * (s + 1) * dil);
+                for (int pr = 0; pr < NP; ++pr) {
+                    const int cur = pr & 1;  // NP is even: every step starts on operand set 0
+                    if (pr + 1 < NP) load_b(Bv[cur ^ 1], pr + 1, tpd + 2 * s * dil);
+                    else load_b(Bv[cur ^ 1], 0, tpd + 2 * (s + 1) * dil);  // (after the last step: discarded)
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                    for (int t = 0; t < 6; ++t) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        acc[2 * pr + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[cur][PA[t]]),
-                                                                                  __builtin_bit_cast(bf16x8, Bv[it & 1][q][PB[t]]), acc[2 * pr + q], 0, 0, 0);
-                    if (pr == NP - 1) {  // last pair of the step: each weight piece is dead after its last term
-                        if (t == 0) load_a_piece(A[cur], 2, gstep + s + 2);
-                        if (t == 2) load_a_piece(A[cur], 1, gstep + s + 2);
-                        if (t == 5) load_a_piece(A[cur], 0, gstep + s + 2);
+                        for (int q = 0; q < 2; ++q)
+                            acc[2 * pr + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[sub][PA[t]]),
+                                                                                      __builtin_bit_cast(bf16x8, Bv[cur][q][PB[t]]), acc[2 * pr + q], 0, 0, 0);
+                        if (pr == NP - 1) {  // last pair of the step: each weight piece is dead after its last term
+                            if (t == 0) load_a_piece(A[sub], 2, gstep + s + 2);
+                            if (t == 2) load_a_piece(A[sub], 1, gstep + s + 2);
+                            if (t == 5) load_a_piece(A[sub], 0, gstep + s + 2);
+                        }
                     }
                 }
             }
+            // issue order: the next pair's six fragment reads in the shadow of the first six MFMAs of each pair
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (pr == NP - 1 && (m == 1 || m == 5 || m == 11)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // issue order: the next pair's six fragment reads in the shadow of the first six MFMAs of each pair
-#pragma unroll
-        for (int i = 0; i < 6; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int pr = 0; pr < NP; ++pr) {
-                const bool more = (pr + 1 < NP) || (s + 1 < S);
-#pragma unroll
-                for (int m = 0; m < 12; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (more && m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (pr == NP - 1 && (m == 1 || m == 5 || m == 11)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
         gstep += S;
     };
 
@@ -462,48 +467,20 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
     }
 }
 
-template <int K>
-inline hipError_t launch_resblock_bf16x6_t(const ResblockSplitParams& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)3 * 2 * RBS_W * 32;
-    auto kern = resblock_bf16x6_kernel<K>;
-    static bool attr_set = false;
-    if (!attr_set) {
+inline hipError_t launch_resblock_bf16x6(int C, const ResblockSplitParams& p, hipStream_t s) {
+    const size_t lds = (C == 16) ? (size_t)3 * RBS16_W * 32 : (size_t)3 * 2 * RBS_W * 32;
+    auto kern = (C == 16) ? resblock16_bf16x6_kernel : resblock_bf16x6_kernel;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[C == 16]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[C == 16] = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
     return hipGetLastError();
 }
-template <int K>
-inline hipError_t launch_resblock16_bf16x6_t(const ResblockSplitParams& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)3 * RBS16_W * 32;
-    auto kern = resblock16_bf16x6_kernel<K>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
-    return hipGetLastError();
-}
-inline bool resblock_bf16x6_has_k(int k) { return k == 3 || k == 7 || k == 11; }
+inline bool resblock_bf16x6_has_k(int k) { return k == 3 || k == 7 || k == 11; }  // odd, (k + 1) / 2 even
 inline int resblock_bf16x6_window(int C) { return C == 16 ? RBS16_W : RBS_W; }
 inline int resblock_bf16x6_steps(int C, int k) { return C == 16 ? (k + 1) / 2 : 2 * k; }  // weight steps per conv
-inline hipError_t launch_resblock_bf16x6(int C, int k, const ResblockSplitParams& p, hipStream_t s) {
-    if (C == 16) switch (k) {
-            case 3: return launch_resblock16_bf16x6_t<3>(p, s);
-            case 7: return launch_resblock16_bf16x6_t<7>(p, s);
-            case 11: return launch_resblock16_bf16x6_t<11>(p, s);
-            default: return hipErrorInvalidValue;
-        }
-    switch (k) {
-        case 3: return launch_resblock_bf16x6_t<3>(p, s);
-        case 7: return launch_resblock_bf16x6_t<7>(p, s);
-        case 11: return launch_resblock_bf16x6_t<11>(p, s);
-        default: return hipErrorInvalidValue;
-    }
-}
 
 }  // namespace parrot
