@@ -387,26 +387,27 @@ inline void bf16x6_tile(int variant, int& bm, int& bn) {
     bm = (variant & 1) ? 64 : 128;
     bn = (variant & 1) ? 256 : 128;
 }
-// the tap counts of the synthesis path get the straight-line kernel, anything else the generic one
-template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW>
-inline hipError_t launch_conv_bf16x6_k(const ConvParams& p, dim3 grid, hipStream_t s) {
-    switch (p.k) {
-        case 1: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 1>(p, grid, s);
-        case 3: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 3>(p, grid, s);
-        case 7: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 7>(p, grid, s);
-        case 9: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 9>(p, grid, s);
-        case 11: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 11>(p, grid, s);
-        default: return launch_conv_bf16x6_t<WAVES_M, WAVES_N, WM, WN, MINW, 0>(p, grid, s);
-    }
-}
+// the (tile, tap count) pairs of the synthesis path get the straight-line kernel, anything else the generic one
 inline hipError_t launch_conv_bf16x6(int variant, const ConvParams& p, hipStream_t s) {
     int bm, bn;
     bf16x6_tile(variant, bm, bn);
     dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
-    if (variant == 3) return launch_conv_bf16x6_k<1, 4, 1, 4, 2>(p, grid, s);
+    if (variant == 3) return p.k == 3 ? launch_conv_bf16x6_t<1, 4, 1, 4, 2, 3>(p, grid, s) : launch_conv_bf16x6_t<1, 4, 1, 4, 2, 0>(p, grid, s);
     if (variant == 2) return p.k == 1 ? launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1>(p, grid, s) : launch_conv_bf16x6_t<2, 2, 2, 1, 3, 0>(p, grid, s);
-    if (variant & 1) return launch_conv_bf16x6_k<1, 4, 2, 2, 2>(p, grid, s);
-    return launch_conv_bf16x6_k<2, 2, 2, 2, 2>(p, grid, s);
+    if (variant & 1) switch (p.k) {
+            case 1: return launch_conv_bf16x6_t<1, 4, 2, 2, 2, 1>(p, grid, s);
+            case 3: return launch_conv_bf16x6_t<1, 4, 2, 2, 2, 3>(p, grid, s);
+            case 7: return launch_conv_bf16x6_t<1, 4, 2, 2, 2, 7>(p, grid, s);
+            case 11: return launch_conv_bf16x6_t<1, 4, 2, 2, 2, 11>(p, grid, s);
+            default: return launch_conv_bf16x6_t<1, 4, 2, 2, 2, 0>(p, grid, s);
+        }
+    switch (p.k) {
+        case 3: return launch_conv_bf16x6_t<2, 2, 2, 2, 2, 3>(p, grid, s);
+        case 7: return launch_conv_bf16x6_t<2, 2, 2, 2, 2, 7>(p, grid, s);
+        case 9: return launch_conv_bf16x6_t<2, 2, 2, 2, 2, 9>(p, grid, s);
+        case 11: return launch_conv_bf16x6_t<2, 2, 2, 2, 2, 11>(p, grid, s);
+        default: return launch_conv_bf16x6_t<2, 2, 2, 2, 2, 0>(p, grid, s);
+    }
 }
 
 }  // namespace parrot

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_bench_fetch.csv + <tag>_bench_write.csv (tools/rocpd_summary.py output of separate rocprofv3 --pmc
+FETCH_SIZE / WRITE_SIZE passes) -> profiles/<tag>_pmc_traffic.json: HBM bytes per launch per kernel, keyed by the
+kernel names bench.py reports (tap-count template argument folded), corrected per tools/pmc_calibrate.py
+(gfx950: FETCH_SIZE counts 0.5 x bytes -> doubled; WRITE_SIZE exact; both in KiB).
+
+    python tools/make_pmc_traffic.py r01d "command that was profiled" """
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def norm(name: str) -> str:
+    name = name.replace(" ", "")
+    m = re.match(r"(conv_bf16x6_kernel<\d+,\d+,\d+,\d+,\d+),\d+>", name)
+    return m.group(1) + ">" if m else name
+
+
+def load(path: str, col: str):
+    tot, calls = {}, {}
+    for r in csv.DictReader(open(path)):
+        if not r.get(col + "_sum"):
+            continue
+        k = norm(r["kernel"])
+        tot[k] = tot.get(k, 0.0) + float(r[col + "_sum"])
+        calls[k] = calls.get(k, 0) + int(r["calls"])
+    return {k: tot[k] / calls[k] for k in tot}
+
+
+def main():
+    tag, cmd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
+    fetch = load(os.path.join(ROOT, "profiles", f"{tag}_bench_fetch.csv"), "FETCH_SIZE")
+    write = load(os.path.join(ROOT, "profiles", f"{tag}_bench_write.csv"), "WRITE_SIZE")
+    out = {"_comment": f"HBM bytes per launch, rocprofv3 PMC passes of `{cmd}`. FETCH_SIZE / WRITE_SIZE in separate passes "
+                       f"(profiles/{tag}_bench_fetch.csv, {tag}_bench_write.csv; KiB per launch averaged over all launches of the kernel, "
+                       "tap-count instantiations of one tile folded); FETCH_SIZE doubled per the gfx950 calibration "
+                       "(profiles/r01_calibration_copy_*.csv: 0.500 x bytes), WRITE_SIZE as is (1.000 x bytes)."}
+    for k in sorted(fetch, key=lambda k: -fetch[k]):
+        if "kernel" not in k:
+            continue
+        w = write.get(k, 0.0)
+        out[k] = {"fetch_kib_raw": round(fetch[k], 1), "write_kib_raw": round(w, 1),
+                  "hbm_bytes_per_launch": int(round((2.0 * fetch[k] + w) * 1024))}
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
