@@ -16,6 +16,7 @@
 #include "conv_bf16x6.h"
 #include "conv_mfma.h"
 #include "conv_mfma16.h"
+#include "conv_valu.h"
 #include "kernels_misc.h"
 #include "resblock_bf16x6.h"
 #include "resblock_fused.h"
@@ -138,8 +139,11 @@ struct parrot_conv {
     int prec = 0;              // 0: exact fp32 MFMA, 1: split-bf16 (6 bf16 MFMAs per product group, fp32 accumulate)
     uint16_t* wfrag16 = nullptr;
     int n_it16 = 0;
+    int valu_kind = 0;         // 1: conv1_valu_kernel<7>, 2: convt_valu_kernel<16,4,2,1> (conv_valu.h); weights in their original layout
+    float* wraw = nullptr;
 
     ~parrot_conv() {
+        if (wraw) (void)hipFree(wraw);
         if (wfrag16) (void)hipFree(wfrag16);
         if (wfrag) (void)hipFree(wfrag);
         if (bias) (void)hipFree(bias);
@@ -185,6 +189,10 @@ static int choose_cfg(int M, int k) {
 }
 
 // Build a plan.  `groups` > 1: torch grouped-conv weight layout (c_out, c_in/groups, k), d.c_in = TOTAL.
+static bool valu_kernels_enabled() {
+    static const bool on = [] { const char* e = getenv("PARROT_VALU_KERNELS"); return !e || atoi(e) != 0; }();
+    return on;
+}
 static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, const float* w, const float* bias) {
     if (!out || !d || !w) return fail(PARROT_E_INVALID, "conv_create: null argument");
     if (d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->dilation <= 0 || groups <= 0 || d->c_in % groups || d->c_out % groups)
@@ -321,6 +329,17 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
         HIP_TRY(hipMalloc((void**)&c->wfrag, pk.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->wfrag, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    // the two narrowest vocoder layers stream through plain fp32 FMA kernels (conv_valu.h) in either precision mode
+    const bool slope01 = d->pre_act != PRE_LRELU || (d->pre_slope >= 0.f && d->pre_slope <= 1.f);
+    if (d->tile_cfg < 0 && groups == 1 && slope01 && d->dilation == 1 && valu_kernels_enabled()) {
+        if (!d->transposed && d->c_out == 1 && d->k == 7 && d->padding == 3 && (d->act == ACT_NONE || d->act == ACT_TANH)) c->valu_kind = 1;
+        if (d->transposed && d->c_out == 16 && d->k == 4 && d->stride == 2 && d->padding == 1 && d->act == ACT_NONE) c->valu_kind = 2;
+        if (c->valu_kind) {
+            const size_t n = (size_t)d->c_in * d->c_out * d->k;
+            HIP_TRY(hipMalloc((void**)&c->wraw, n * sizeof(float)));
+            HIP_TRY(hipMemcpy(c->wraw, w, n * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     if (bias) {
         HIP_TRY(hipMalloc((void**)&c->bias, (size_t)d->c_out * sizeof(float)));
         HIP_TRY(hipMemcpy(c->bias, bias, (size_t)d->c_out * sizeof(float), hipMemcpyHostToDevice));
@@ -336,6 +355,22 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     if (B <= 0 || Tin <= 0) return fail(PARROT_E_INVALID, "conv_run: empty batch or sequence");
     const int Tout = c->out_len(Tin);
     if (Tout <= 0) return fail(PARROT_E_INVALID, "conv_run: sequence shorter than the kernel");
+    if (c->valu_kind && !res && epi == EPI_STORE && x_bstride <= 0 && y_bstride <= 0) {
+        ConvValuParams q{};
+        q.x = x; q.w = c->wraw; q.bias = c->bias; q.y = y;
+        q.B = B; q.Cin = c->d.c_in; q.Tin = Tin; q.Tout = Tout;
+        q.slope = c->d.pre_act == PRE_LRELU ? c->d.pre_slope : 1.f;
+        q.act = c->d.act;
+        q.row_len = row_len; q.row_len_mul = row_len_mul;
+        ProfRec rec{};
+        const double macs = (double)B * c->d.c_out * c->d.c_in * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
+        if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 6 + c->valu_kind, 2.0 * macs, 4.0 * B * ((double)c->d.c_in * Tin + (double)c->d.c_out * Tout), s));
+        if (c->valu_kind == 1) hipLaunchKernelGGL(conv1_valu_kernel<7>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((convt_valu_kernel<16, 4, 2, 1>), dim3((Tin + 255) / 256, B), dim3(256), 0, s, q);
+        HIP_TRY(hipGetLastError());
+        if (g_prof_on) TRY(prof_close(rec, s));
+        return PARROT_OK;
+    }
     ConvParams p{};
     p.x = x; p.wfrag = c->wfrag; p.bias = c->bias; p.res = res; p.y = y;
     p.B = B; p.Cin = c->Cin; p.Tin = Tin; p.M = c->M; p.Cout = c->Cout;
