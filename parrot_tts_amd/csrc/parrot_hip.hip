@@ -555,21 +555,22 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     }
     // ResBlock1 blocks of the 32- and 16-channel stages under the split-bf16 scheme: one concatenated weight stream per
     // block for the fused pair kernels (resblock_bf16x6.h), [conv][step][piece][lane][8 bf16] + padding for the prefetch past the end.
-    //   32 channels: the conv plans' own streams (step = chunk * k + tap);
+    //   32 / 64 channels: the conv plans' own streams ([row tile][chunk * k + tap]);
     //   16 channels: packed here for the 16x16x32 MFMA (step = tap pair; lane = row l&15, channels 8(g&1).., tap 2*step + (g>>1)).
     v->rb_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
     for (int i = 0; i < cfg->n_stages; ++i)
         for (int j = 0; j < cfg->n_kernels; ++j) {
             const int rk = cfg->resblock_kernel_sizes[j], C = v->chan(i);
-            if (cfg->resblock_type != 1 || !(C == 32 || C == 16) || !resblock_bf16x6_has_k(rk) || per_rb > RBS_MAX_CONVS) continue;
+            if (cfg->resblock_type != 1 || !resblock_bf16x6_has(C, rk) || per_rb > RBS_MAX_CONVS) continue;
             const int base = (i * cfg->n_kernels + j) * per_rb;
             const int steps = resblock_bf16x6_steps(C, rk);
             const size_t step_b = 3072, conv_b = (size_t)steps * step_b;
-            if (C == 32) {
+            if (C >= 32) {  // the plans' streams are already [row tile][chunk * k + tap]
                 bool ok = true;
                 for (int q = 0; q < per_rb; ++q) {
                     const parrot_conv* pc = v->rb[base + q].get();
-                    ok = ok && pc->prec == 1 && pc->wfrag16 && pc->nchunks == 2 && pc->n_it16 == steps && pc->M == 32;
+                    ok = ok && pc->prec == 1 && pc->wfrag16 && pc->nchunks == C / 16 && (C / 32) * pc->n_it16 == steps && pc->M == C &&
+                         tile_cfg(pc->cfg).bm == C;
                 }
                 if (!ok) continue;
                 // (the kernel's in-place prefetch after the last tap reads "the next conv's" tap 0 of both chunks: one
@@ -702,7 +703,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
     const int per_rb = 2 * c.n_dil, k = c.resblock_kernel_sizes[j], C = v->chan(stage);
     const int base = (stage * c.n_kernels + j) * per_rb;
     const int W = resblock_bf16x6_window(C), steps = resblock_bf16x6_steps(C, k);
-    const int hmax = rbs_hmax() * (W / RBS_W);  // the same fraction of the window
+    const int hmax = rbs_hmax() * W / RBS_W;  // the same fraction of the window
     const uint16_t* stream = v->rb_stream[(size_t)stage * c.n_kernels + j];
     const float* src = x;
     int m0 = 0, n_launch = 0;

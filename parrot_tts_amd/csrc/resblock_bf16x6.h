@@ -49,18 +49,23 @@ struct ResblockSplitParams {
     int row_len_mul;
 };
 
-constexpr int RBS_W = 384;
+constexpr int RBS_W = 384;  // 32-channel window (the 64-channel kernel uses half: the same 72 KiB of LDS)
 
+// NCH = channel chunks of 16: 2 -> 32 channels, 4 waves side by side (window 384);
+//                              4 -> 64 channels, 2 (row tiles) x 2 (column halves) waves (window 192).
+template <int NCH>
 __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockSplitParams p) {
-    constexpr int C = 32, NCH = 2, NTW = 3, W = RBS_W;
+    constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = 4 / WAVES_M, NTW = 3, W = WAVES_N * NTW * 32;
     const int K = p.k;
     constexpr int CH_BYTES = W * 32, PIECE_BYTES = NCH * CH_BYTES;  // [piece][chunk][col][16 ch] bf16
-    static_assert(4 * NTW * 32 == W, "4 waves x NTW tiles cover the window");
+    static_assert(NCH == 2 || NCH == 4, "32 or 64 channels");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // 3 * PIECE_BYTES
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N;  // row tile (32 output channels) of this wave
+    const int wn = wave % WAVES_N;  // column group (96 columns)
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const int b = blockIdx.x / p.tiles;
@@ -73,12 +78,12 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
     bool tok[NTW];  // ... inside the sequence
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        col[nt] = wave * (NTW * 32) + nt * 32 + l31;
+        col[nt] = wn * (NTW * 32) + nt * 32 + l31;
         const int t = t_base + col[nt];
         tok[nt] = t >= 0 && t < Tlim;
     }
 
-    // ---- R <- x window, in the C/D layout: row m = (r & 3) + 8 (r >> 2) + 4 half, column = lane & 31 -------------
+    // ---- R <- x window, in the C/D layout: row m = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, column = lane & 31 -----
     f32x16 R[NTW], acc[NTW];
     {
         const size_t xaddr = reinterpret_cast<size_t>(p.x + (size_t)b * C * p.T);
@@ -91,18 +96,18 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
             const int voff = tok[nt] ? (t_base + col[nt]) * 4 + 4 * half * row_bytes : (int)0x80000000;  // out of range -> 0
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                R[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, ((r & 3) + 8 * (r >> 2)) * row_bytes, 0));
+                R[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, (32 * wm + (r & 3) + 8 * (r >> 2)) * row_bytes, 0));
         }
     }
 
     // ---- accumulator tile -> operand buffer: (leaky ReLU,) sequence mask, 3-way split, two 8-byte stores per
-    //      (tile, chunk, piece, row group): rows 8q+4g+{0..3} of this half are channels 16q + 8g + 4 half + {0..3}
+    //      (tile, chunk, piece, row group): rows 8q+4g+{0..3} of this half are channels 16 (2 wm + q) + 8g + 4 half + {0..3}
     auto write_p = [&](const f32x16 (&v)[NTW]) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int swz = (col[nt] >> 3) & 1;
 #pragma unroll
-            for (int q = 0; q < NCH; ++q)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     unsigned q0[2], q1[2], q2[2];
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
                         }
                         split3_pk(v0, v1, q0[e], q1[e], q2[e]);
                     }
-                    char* dst = smem_raw + q * CH_BYTES + col[nt] * 32 + ((g ^ swz) * 16) + 8 * half;
+                    char* dst = smem_raw + (2 * wm + q) * CH_BYTES + col[nt] * 32 + ((g ^ swz) * 16) + 8 * half;
                     *reinterpret_cast<uint2*>(dst) = uint2{q0[0], q0[1]};
                     *reinterpret_cast<uint2*>(dst + PIECE_BYTES) = uint2{q1[0], q1[1]};
                     *reinterpret_cast<uint2*>(dst + 2 * PIECE_BYTES) = uint2{q2[0], q2[1]};
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
     };
 
     // ---- weights: one buffer descriptor, per-lane constant offset, scalar step offset ----------------------------
+    // stream order: [conv][row tile][chunk * K + tap]; this wave walks its own row tile's steps
     const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(p.wstream));
     const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<size_t>(p.wstream) >> 32));
     const __amdgpu_buffer_rsrc_t wrsrc =
@@ -135,10 +141,12 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
     auto load_a_piece = [&](s16x8 (&a)[3], int pc, int gstep) __attribute__((always_inline)) {
         a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, gstep * 3072, 0));
     };
+    const int conv_steps = WAVES_M * NCH * K;  // steps of one conv in the stream
+    int gbase = wm * NCH * K;                  // this wave's first step of the current conv
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
-        load_a_piece(A[0], pc, 0);  // (tap 0, chunk 0)
-        load_a_piece(A[1], pc, K);  // (tap 0, chunk 1)
+        load_a_piece(A[0], pc, gbase);      // (tap 0, chunk 0)
+        load_a_piece(A[1], pc, gbase + K);  // (tap 0, chunk 1)
     }
 
     if (edge) {
@@ -153,7 +161,6 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
     constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
     constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
     const int center = (K - 1) / 2;
-    int gbase = 0;  // first step of the current conv in the stream (step = chunk * K + tap)
     auto load_b = [&](s16x8 (&bb)[NTW][3], int ch, int shift) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -163,34 +170,36 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
             for (int pc = 0; pc < 3; ++pc) bb[nt][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
     };
-    // one conv out of P into acc (initialised by the caller).  Tap loop; per tap two steps (channel chunk 0 with
-    // register sets 0, chunk 1 with sets 1).  On entry the weight sets hold this conv's (tap 0, chunk 0 / 1); each
-    // piece is re-fetched in place for the next tap (after the last tap: the next conv's tap 0) right after its last
-    // use, and the operand fragments of the next step are read during the current one.
+    // one conv out of P into acc (initialised by the caller).  Tap loop; per tap NCH steps (input-channel chunk ch with
+    // register sets ch & 1).  On entry the weight sets hold this conv's (tap 0, chunk 0 / 1); each piece is re-fetched
+    // in place for the step two ahead (chunk + 2 of this tap, else chunk + 2 - NCH of the next tap, else of the next
+    // conv's tap 0) right after its last use, and the operand fragments of the next step are read during the current one.
     // (A last, discarded fragment read follows the final step; the stream is padded by one conv for the prefetch.)
     auto conv = [&](int dil) __attribute__((always_inline)) {
         load_b(Bv[0], 0, -center * dil);
         for (int j = 0; j < K; ++j) {
             const int shift = (j - center) * dil;
-            const int n0 = (j + 1 < K) ? gbase + j + 1 : gbase + 2 * K;  // (tap + 1, chunk 0); chunk 1 is K steps further
+            const int n0 = (j + 1 < K) ? gbase + j + 1 : gbase + conv_steps;  // (next tap, chunk 0); chunk c is c * K steps further
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-                if (ch == 0) load_b(Bv[1], 1, shift);
-                else load_b(Bv[0], 0, shift + dil);
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int set = ch & 1;
+                if (ch + 1 < NCH) load_b(Bv[set ^ 1], ch + 1, shift);
+                else load_b(Bv[set ^ 1], 0, shift + dil);
+                const int nx = (ch + 2 < NCH) ? gbase + (ch + 2) * K + j : n0 + (ch + 2 - NCH) * K;  // two steps ahead
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[ch][PA[t]]),
-                                                                          __builtin_bit_cast(bf16x8, Bv[ch][nt][PB[t]]), acc[nt], 0, 0, 0);
-                    if (t == 0) load_a_piece(A[ch], 2, n0 + ch * K);
-                    if (t == 2) load_a_piece(A[ch], 1, n0 + ch * K);
-                    if (t == 5) load_a_piece(A[ch], 0, n0 + ch * K);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[set][PA[t]]),
+                                                                          __builtin_bit_cast(bf16x8, Bv[set][nt][PB[t]]), acc[nt], 0, 0, 0);
+                    if (t == 0) load_a_piece(A[set], 2, nx);
+                    if (t == 2) load_a_piece(A[set], 1, nx);
+                    if (t == 5) load_a_piece(A[set], 0, nx);
                 }
             }
             // issue order: one memory instruction in the shadow of each MFMA (see conv_bf16x6.h)
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
+            for (int ch = 0; ch < NCH; ++ch) {
                 int ds_left = 3 * NTW;
 #pragma unroll
                 for (int m = 0; m < 6 * NTW; ++m) {
@@ -205,11 +214,11 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        gbase += 2 * K;
+        gbase += conv_steps;
     };
     auto bias_rows = [&](const float* __restrict__ bias, float (&bv)[16]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * half];
+        for (int r = 0; r < 16; ++r) bv[r] = bias[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half];
     };
 
     for (int m = 0; m < p.n_conv; m += 2) {
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
     }
 
     // ---- write the central TT columns (registers -> global, 128-byte runs per row) ---------------------------------
-    float* __restrict__ yb = p.y + (size_t)b * C * p.T;
+    float* __restrict__ yb = p.y + (size_t)b * C * p.T + (size_t)(32 * wm) * p.T;
     const bool has_acc = p.epi != EPI_STORE;
     const bool do_div = p.epi == EPI_ADD_DIV;
 #pragma unroll
@@ -468,19 +477,24 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
 }
 
 inline hipError_t launch_resblock_bf16x6(int C, const ResblockSplitParams& p, hipStream_t s) {
-    const size_t lds = (C == 16) ? (size_t)3 * RBS16_W * 32 : (size_t)3 * 2 * RBS_W * 32;
-    auto kern = (C == 16) ? resblock16_bf16x6_kernel : resblock_bf16x6_kernel;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[C == 16]) {
+    const size_t lds = (size_t)3 * 2 * RBS_W * 32;  // the same 72 KiB for every channel count
+    auto kern = (C == 16) ? resblock16_bf16x6_kernel : (C == 64) ? resblock_bf16x6_kernel<4> : resblock_bf16x6_kernel<2>;
+    static bool attr_set[3] = {false, false, false};
+    const int slot = (C == 16) ? 0 : (C == 64) ? 2 : 1;
+    if (!attr_set[slot]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set[C == 16] = true;
+        attr_set[slot] = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
     return hipGetLastError();
 }
-inline bool resblock_bf16x6_has_k(int k) { return k == 3 || k == 7 || k == 11; }  // odd, (k + 1) / 2 even
-inline int resblock_bf16x6_window(int C) { return C == 16 ? RBS16_W : RBS_W; }
-inline int resblock_bf16x6_steps(int C, int k) { return C == 16 ? (k + 1) / 2 : 2 * k; }  // weight steps per conv
+// odd tap counts with (k + 1) / 2 even; at 64 channels the 192-column window loses too much to the halo of k = 11
+inline bool resblock_bf16x6_has(int C, int k) {
+    if (C == 64) return k == 3 || k == 7;
+    return (C == 32 || C == 16) && (k == 3 || k == 7 || k == 11);
+}
+inline int resblock_bf16x6_window(int C) { return C == 16 ? RBS16_W : C == 64 ? RBS_W / 2 : RBS_W; }
+inline int resblock_bf16x6_steps(int C, int k) { return C == 16 ? (k + 1) / 2 : (C / 32) * (C / 16) * k; }  // weight steps per conv
 
 }  // namespace parrot
