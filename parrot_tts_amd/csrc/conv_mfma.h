@@ -129,6 +129,44 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     const bool plain = p.u == 1;
     const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    if ((p.u == 4 || p.u == 2) && p.Tout == p.Ncols * p.u) {
+        // transposed conv with stride 4 / 2: the four consecutive rows a lane holds per register group (C/D layout) are
+        // the 4 phases of ONE output channel (or 2 phases of two), i.e. consecutive output samples: 16-/8-byte stores
+        // instead of 16 strided 4-byte ones, one bias load per group.
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int mbase = m_wave + mt * 32 + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) {
+                const int n = n_wave + nt * 32 + l31;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mbase + 8 * q;
+                    const bool ok = m < p.M && n < p.Ncols;
+                    if (p.u == 4) {
+                        const int o = m >> 2;
+                        const float bs = (p.bias && ok) ? p.bias[o] : 0.f;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[mt][nt][4 * q + e] + bs, p.act);
+                        if (ok) *reinterpret_cast<f32x4*>(yb + (size_t)o * p.Tout + 4 * n) = v;
+                    } else {
+                        const int o = m >> 1;
+                        const float b0 = (p.bias && ok) ? p.bias[o] : 0.f, b1 = (p.bias && ok && m + 2 < p.M) ? p.bias[o + 1] : 0.f;
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        f32x2_t v0, v1;
+                        v0[0] = apply_act(acc[mt][nt][4 * q + 0] + b0, p.act);
+                        v0[1] = apply_act(acc[mt][nt][4 * q + 1] + b0, p.act);
+                        v1[0] = apply_act(acc[mt][nt][4 * q + 2] + b1, p.act);
+                        v1[1] = apply_act(acc[mt][nt][4 * q + 3] + b1, p.act);
+                        if (ok) *reinterpret_cast<f32x2_t*>(yb + (size_t)o * p.Tout + 2 * n) = v0;
+                        if (ok && m + 2 < p.M) *reinterpret_cast<f32x2_t*>(yb + (size_t)(o + 1) * p.Tout + 2 * n) = v1;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (p.u > 1) {
         // transposed conv: GEMM row m = o*u + phase, column n = input step -> out[o][n*u + phase]; stores only.
         // o = m / u via a 16-bit reciprocal of the small in-tile remainder (exact for rem < 64, u <= 64).
