@@ -60,15 +60,21 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K>
+// SUBS > 1 (1x1 convs only): SUBS 16-channel sub-slabs are staged per barrier and no halo columns at all -- a 1x1 conv
+// otherwise pays one barrier, one conversion pass over tile + 64 halo columns and one pipeline bubble per MFMA step.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kernel(const ConvParams p) {
+    static_assert(SUBS == 1 || K == 1, "sub-slab staging is for 1x1 convs");
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
-    constexpr int COLS = BN + CONV_HALO;           // staged columns per chunk
+    constexpr int COLS = BN + (SUBS > 1 ? 0 : CONV_HALO);  // staged columns per chunk
     constexpr int PIECE_BYTES = COLS * 32;         // [col][16 ch] bf16
-    constexpr int BUF_BYTES = 3 * PIECE_BYTES;
-    constexpr int ITEMS = (COLS * 2 + NT - 1) / NT;  // (column, channel-octet) items per thread
+    constexpr int SUB_BYTES = 3 * PIECE_BYTES;     // one 16-channel sub-slab
+    constexpr int BUF_BYTES = SUBS * SUB_BYTES;
+    constexpr int LIVE = SUBS * COLS * 2;          // (sub-slab, channel-octet, column) items per chunk
+    constexpr int ITEMS = (LIVE + NT - 1) / NT;    // ... per thread
+    constexpr int KS = K * SUBS;                   // MFMA steps per chunk (static path)
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [2][3][COLS][16] bf16
 
@@ -104,15 +110,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     static_for<ITEMS>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int item = tid + NT * i;
-        const int oct = item / COLS;
-        const int col = item - oct * COLS;
+        const int so = item / COLS;  // sub-slab * 2 + channel octet (wave-uniform)
+        const int col = item - so * COLS;
         const int tin = t0 - p.pad_left + col;
-        voff[i] = (oct < 2 && tin >= 0 && tin < Tlim) ? tin * 4 : (int)0x80000000;  // (idle slots read out of range too)
-        soct[i] = __builtin_amdgcn_readfirstlane(min(oct, 1) * 8) * row_bytes;
+        voff[i] = (item < LIVE && tin >= 0 && tin < Tlim) ? tin * 4 : (int)0x80000000;  // (idle slots read out of range too)
+        soct[i] = __builtin_amdgcn_readfirstlane(min(so, 2 * SUBS - 1) * 8) * row_bytes;
     });
     float stage[ITEMS][8];
     auto load_slab = [&](int c) __attribute__((always_inline)) {
-        const int cbase = c * 16 * row_bytes;
+        const int cbase = c * (16 * SUBS) * row_bytes;
         static_for<ITEMS>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -125,8 +131,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
         static_for<ITEMS>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int item = tid + NT * i;
-            const int oct = item / COLS;
-            const int col = item - oct * COLS;
+            const int so = item / COLS, sub = so >> 1, oct = so & 1;
+            const int col = item - so * COLS;
             unsigned q0[4], q1[4], q2[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -134,11 +140,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
                 const float v0 = stage[i][2 * e], v1 = stage[i][2 * e + 1];
                 split3_pk(max_nc(v0, v0 * slope), max_nc(v1, v1 * slope), q0[e], q1[e], q2[e]);
             }
-            if (oct < 2) {
+            if (item < LIVE) {
                 const uint4 v0 = {q0[0], q0[1], q0[2], q0[3]}, v1 = {q1[0], q1[1], q1[2], q1[3]}, v2 = {q2[0], q2[1], q2[2], q2[3]};
                 // the two channel octets of a column swap places on odd 8-column groups: with a 32 B column
                 // stride this makes every ds_read_b128 lane group hit 16 distinct 16 B slots (no 2-way conflict)
-                const int off = col * 32 + ((oct ^ ((col >> 3) & 1)) * 16);
+                const int off = sub * SUB_BYTES + col * 32 + ((oct ^ ((col >> 3) & 1)) * 16);
                 *reinterpret_cast<uint4*>(dst + off) = v0;
                 *reinterpret_cast<uint4*>(dst + PIECE_BYTES + off) = v1;
                 *reinterpret_cast<uint4*>(dst + 2 * PIECE_BYTES + off) = v2;
@@ -169,7 +175,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
         abase[mt] = __builtin_amdgcn_readfirstlane((int)((blockIdx.y * (BM / 32) + wm * WM + mt) * p.n_it * 3072));
     const unsigned lane16 = lane * 16;
     // (workgroup b runs on XCD b % 8, so the rotation must vary with tn / 8 to differ between neighbours on one L2)
-    const int rot = __builtin_amdgcn_readfirstlane((tn + (tn >> 3)) % p.nchunks);  // (% runs on the VALU: pin the result to an SGPR)
+    const int nsup = p.nchunks / SUBS;  // chunks of 16 * SUBS channels (the host only picks SUBS > 1 when this divides)
+    const int rot = __builtin_amdgcn_readfirstlane((tn + (tn >> 3)) % nsup);  // (% runs on the VALU: pin the result to an SGPR)
     // Two operand register sets in ping-pong: the step after the current one is always fetched straight into the
     // OTHER set, so the loop has no register copies (48 v_mov per step cost as much issue time as the 24 MFMAs).
     s16x8 a0[WM][3], b0[WN][3], a1[WM][3], b1[WN][3];
@@ -218,12 +225,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
             for (int mt = 0; mt < WM; ++mt)
                 a[mt][pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, abase[mt] + soff, 0));
         };
-        auto next_chunk = [&](int q) { return (q + 1 == p.nchunks) ? 0 : q + 1; };
+        auto next_chunk = [&](int q) { return (q + 1 == nsup) ? 0 : q + 1; };
         int cc = rot, cn = next_chunk(rot);
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
-            load_a_piece(A[0], pc, cc * K * 3072);
-            load_a_piece(A[1], pc, (K > 1 ? cc * K + 1 : cn * K) * 3072);
+            load_a_piece(A[0], pc, cc * KS * 3072);
+            load_a_piece(A[1], pc, (KS > 1 ? cc * KS + 1 : cn * KS) * 3072);
         }
         load_slab(rot);
         store_slab(0);
@@ -237,16 +244,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
 #endif
             load_b(Bv[PAR], xs, 0);
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
+            for (int j = 0; j < KS; ++j) {  // step j: sub-slab j / K, tap j % K
                 const int cur = (PAR + j) & 1;
-                const int tq = (j + 2 < K) ? cc : (K == 1 ? cn2 : cn);  // step + 2 in the flat order
-                const int tj = (j + 2 < K) ? j + 2 : (K == 1 ? 0 : j + 2 - K);
+                const int tq = (j + 2 < KS) ? cc : (KS == 1 ? cn2 : cn);  // step + 2 in the flat order
+                const int tj = (j + 2 < KS) ? j + 2 : (KS == 1 ? 0 : j + 2 - KS);
 #ifdef EXP_A_CONST
                 const int soff = 0; (void)tq; (void)tj;
 #else
-                const int soff = (tq * K + tj) * 3072;
+                const int soff = (tq * KS + tj) * 3072;
 #endif
-                if (j + 1 < K) load_b(Bv[cur ^ 1], xs, j + 1);
+                if (j + 1 < KS) load_b(Bv[cur ^ 1], xs + ((j + 1) / K) * SUB_BYTES, (j + 1) % K);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
 #pragma unroll
@@ -268,8 +275,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
 #pragma unroll
             for (int i = 0; i < 3 * WN; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // tap 0 fragments
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                int ds_left = (j + 1 < K) ? 3 * WN : 0, slab_left = (j == 0) ? ITEMS * 8 : 0;
+            for (int j = 0; j < KS; ++j) {
+                int ds_left = (j + 1 < KS) ? 3 * WN : 0, slab_left = (j == 0) ? ITEMS * 8 : 0;
 #pragma unroll
                 for (int m = 0; m < NMF; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -300,9 +307,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
             cc = cn;
             cn = cn2;
         };
-        for (int c = 0; c < p.nchunks; c += 2) {
+        for (int c = 0; c < nsup; c += 2) {
             chunk(std::integral_constant<int, 0>{}, c);
-            if (c + 1 < p.nchunks) chunk(std::integral_constant<int, (K & 1)>{}, c + 1);
+            if (c + 1 < nsup) chunk(std::integral_constant<int, (KS & 1)>{}, c + 1);
         }
     } else {
         load_a(a0, rot * p.k);
@@ -362,11 +369,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     conv_epilogue<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1>
 inline hipError_t launch_conv_bf16x6_t(const ConvParams& p, dim3 grid, hipStream_t s) {
     constexpr int BN = WAVES_N * WN * 32;
-    const size_t lds = (size_t)2 * 3 * (BN + CONV_HALO) * 32;
-    auto kern = conv_bf16x6_kernel<WAVES_M, WAVES_N, WM, WN, MINW, K>;
+    const size_t lds = (size_t)2 * SUBS * 3 * (BN + (SUBS > 1 ? 0 : CONV_HALO)) * 32;
+    auto kern = conv_bf16x6_kernel<WAVES_M, WAVES_N, WM, WN, MINW, K, SUBS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -393,7 +400,10 @@ inline hipError_t launch_conv_bf16x6(int variant, const ConvParams& p, hipStream
     bf16x6_tile(variant, bm, bn);
     dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
     if (variant == 3) return p.k == 3 ? launch_conv_bf16x6_t<1, 4, 1, 4, 2, 3>(p, grid, s) : launch_conv_bf16x6_t<1, 4, 1, 4, 2, 0>(p, grid, s);
-    if (variant == 2) return p.k == 1 ? launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1>(p, grid, s) : launch_conv_bf16x6_t<2, 2, 2, 1, 3, 0>(p, grid, s);
+    if (variant == 2) {
+        if (p.k == 1 && p.nchunks % 4 == 0) return launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1, 4>(p, grid, s);  // 64 channels per barrier
+        return p.k == 1 ? launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1>(p, grid, s) : launch_conv_bf16x6_t<2, 2, 2, 1, 3, 0>(p, grid, s);
+    }
     if (variant & 1) switch (p.k) {
             case 1: return launch_conv_bf16x6_t<1, 4, 2, 2, 2, 1>(p, grid, s);
             case 3: return launch_conv_bf16x6_t<1, 4, 2, 2, 2, 3>(p, grid, s);
