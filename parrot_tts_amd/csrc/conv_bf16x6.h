@@ -158,9 +158,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     conv_acc_init<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 
     // A stream: n_it = nchunks * k steps per m-tile, 3 KiB per step ([piece][lane][8 bf16]).
-    // Chunks are visited in an order rotated by the tile index: workgroups running side by side then stream
-    // DIFFERENT weight lines at any moment instead of all hammering the same L2 channel in lockstep (the order
-    // depends on the column tile only, so a batch row's result does not depend on the batch it sits in).
     // Weight stream addressing: one buffer descriptor (SGPR quad) for the whole packed stream, a constant per-lane byte
     // offset (voffset) and a wave-uniform scalar offset per (m-tile, step) (soffset): each fetch is
     // `buffer_load_dwordx4 v, v_lane, s[rsrc], s_off offen` -- no 64-bit VALU address math per step and no
@@ -174,9 +171,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bf16x6_kerne
     for (int mt = 0; mt < WM; ++mt)
         abase[mt] = __builtin_amdgcn_readfirstlane((int)((blockIdx.y * (BM / 32) + wm * WM + mt) * p.n_it * 3072));
     const unsigned lane16 = lane * 16;
-    // (workgroup b runs on XCD b % 8, so the rotation must vary with tn / 8 to differ between neighbours on one L2)
     const int nsup = p.nchunks / SUBS;  // chunks of 16 * SUBS channels (the host only picks SUBS > 1 when this divides)
-    const int rot = __builtin_amdgcn_readfirstlane((tn + (tn >> 3)) % nsup);  // (% runs on the VALU: pin the result to an SGPR)
+    // (A per-tile rotation of the chunk order, meant to spread neighbouring workgroups over different L2 lines, measured
+    //  +2 % before the streams were buffer-addressed and -0.8 % after -- co-resident workgroups now share weight lines in
+    //  L1 -- so every workgroup walks the chunks from 0; the loop below still supports any starting chunk.)
+    constexpr int rot = 0;  // (% runs on the VALU: pin the result to an SGPR)
     // Two operand register sets in ping-pong: the step after the current one is always fetched straight into the
     // OTHER set, so the loop has no register copies (48 v_mov per step cost as much issue time as the 24 MFMAs).
     s16x8 a0[WM][3], b0[WN][3], a1[WM][3], b1[WN][3];
