@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-fp32 pass")
     ap.add_argument("--precision", choices=["f32", "bf16x6"], default=os.environ.get("PARROT_BENCH_PRECISION", "bf16x6"),
-                    help="product evaluation of the conv kernel for layers with >= 64 output channels (fp32 data either way)")
+                    help="product evaluation of the conv kernels for layers with >= 16 channels (fp32 data either way)")
     a = ap.parse_args()
 
     rank, world, local = pdist.init_from_env("nccl")

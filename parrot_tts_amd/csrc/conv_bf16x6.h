@@ -384,11 +384,11 @@ inline hipError_t launch_conv_bf16x6_t(const ConvParams& p, dim3 grid, hipStream
 }
 
 // bf16x6 tile variants: 0 = 128x128 (waves 2x2), 1 = 64x256 (waves 1x4); wave tile 64x64, 2 waves per SIMD;
-//                      2 = 128x64 (waves 2x2, wave tile 64x32, 3 waves per SIMD) for 1x1 convs;
+//                      2 = 128x64 (waves 2x2, wave tile 64x32, 3 waves per SIMD) for 1x1 convs and sequences <= 64;
 //                      3 = 32x512 (waves 1x4, wave tile 32x128) for 32-channel layers.
 // (Measured and dropped: a 64x128 wave tile at 1 wave per SIMD, -8 %.)
 inline void bf16x6_tile(int variant, int& bm, int& bn) {
-    if (variant == 2) { bm = 128; bn = 64; return; }   // wave tile 64x32, 3 waves per SIMD: 1x1 convs only
+    if (variant == 2) { bm = 128; bn = 64; return; }   // wave tile 64x32, 3 waves per SIMD
     if (variant == 3) { bm = 32; bn = 512; return; }
     bm = (variant & 1) ? 64 : 128;
     bn = (variant & 1) ? 256 : 128;
@@ -401,7 +401,12 @@ inline hipError_t launch_conv_bf16x6(int variant, const ConvParams& p, hipStream
     if (variant == 3) return p.k == 3 ? launch_conv_bf16x6_t<1, 4, 1, 4, 2, 3>(p, grid, s) : launch_conv_bf16x6_t<1, 4, 1, 4, 2, 0>(p, grid, s);
     if (variant == 2) {
         if (p.k == 1 && p.nchunks % 4 == 0) return launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1, 4>(p, grid, s);  // 64 channels per barrier
-        return p.k == 1 ? launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1>(p, grid, s) : launch_conv_bf16x6_t<2, 2, 2, 1, 3, 0>(p, grid, s);
+        switch (p.k) {  // (k > 1: sequences of <= 64 steps, i.e. the TTE encoder side)
+            case 1: return launch_conv_bf16x6_t<2, 2, 2, 1, 3, 1>(p, grid, s);
+            case 3: return launch_conv_bf16x6_t<2, 2, 2, 1, 3, 3>(p, grid, s);
+            case 9: return launch_conv_bf16x6_t<2, 2, 2, 1, 3, 9>(p, grid, s);
+            default: return launch_conv_bf16x6_t<2, 2, 2, 1, 3, 0>(p, grid, s);
+        }
     }
     if (variant & 1) switch (p.k) {
             case 1: return launch_conv_bf16x6_t<1, 4, 2, 2, 2, 1>(p, grid, s);

@@ -398,7 +398,8 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     if (c->prec == 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
         // better (76 vs 61 TF on the qkv projection); every other layer is faster on the 64x64 wave tile
-        variant16 = (cfg == 2) ? 3 : (cfg == 0 && c->kk == 1) ? 2 : cfg;
+        // (and so are sequences of <= 64 steps -- the TTE encoder side -- which would leave half of a 128-column tile empty)
+        variant16 = (cfg == 2) ? 3 : (cfg == 0 && (c->kk == 1 || p.Ncols <= 64)) ? 2 : cfg;
         bf16x6_tile(variant16, t.bm, t.bn);
     }
     p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
