@@ -845,6 +845,7 @@ struct FftLayer {
     std::unique_ptr<parrot_conv> qkv, in_proj, out_proj, wo, conv1, conv2;
     float *an_w = nullptr, *an_b = nullptr, *cn_w = nullptr, *cn_b = nullptr;
     int heads = 1;
+    bool merged = false;  // qkv holds in_proj * qkv, wo holds wo * out_proj (in_proj / out_proj unused)
     ~FftLayer() {
         for (float* p : {an_w, an_b, cn_w, cn_b})
             if (p) (void)hipFree(p);
@@ -870,11 +871,44 @@ static int build_fft(std::unique_ptr<FftLayer>& slot, const parrot_tte_cfg& c, i
     const int D = c.d_model, F = c.n_filter_ffn;
     if (D % heads) return fail(PARROT_E_INVALID, "tte_create: d_model % n_head != 0");  // fft.py:44
     L->heads = heads;
-    TRY(make_conv(L->qkv, D, 3 * D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.qkv, nullptr));
-    // MHA in_proj: three bias-free (D,D) projections of three different inputs = a grouped 1x1 conv
-    TRY(make_conv(L->in_proj, 3 * D, 3 * D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.in_proj, nullptr, 3));
-    TRY(make_conv(L->out_proj, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.out_proj, nullptr));
-    TRY(make_conv(L->wo, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.wo, nullptr));
+    // The reference projects twice on each side of the attention core (quirk Q3: the block's own bias-free qkv / wo
+    // Linear around nn.MultiheadAttention's bias-free in_proj / out_proj, fft.py:48-57).  Two linear maps with
+    // nothing in between are ONE linear map: the products are formed here in fp64 and rounded once to fp32
+    //     W_qkv' = blockdiag(W_in_q, W_in_k, W_in_v) * W_qkv   (3D x D),     W_o' = W_wo * W_out   (D x D)
+    // which removes two launches per block (PARROT_TTE_MERGE=0 keeps the four separate projections).
+    static const bool merge = [] { const char* e = getenv("PARROT_TTE_MERGE"); return !e || atoi(e) != 0; }();
+    L->merged = merge;
+    if (merge) {
+        std::vector<float> wq((size_t)3 * D * D), wo((size_t)D * D);
+        std::vector<double> row(D);
+        for (int g = 0; g < 3; ++g)
+            for (int i = 0; i < D; ++i) {  // row i of group g: sum_j in_proj[gD+i][j] * qkv[gD+j][:]
+                std::fill(row.begin(), row.end(), 0.0);
+                for (int j = 0; j < D; ++j) {
+                    const double a = w.in_proj[((size_t)g * D + i) * D + j];
+                    const float* q = w.qkv + ((size_t)g * D + j) * D;
+                    for (int c2 = 0; c2 < D; ++c2) row[c2] += a * (double)q[c2];
+                }
+                for (int c2 = 0; c2 < D; ++c2) wq[((size_t)g * D + i) * D + c2] = (float)row[c2];
+            }
+        for (int i = 0; i < D; ++i) {  // W_o'[i][:] = sum_j wo[i][j] * out_proj[j][:]
+            std::fill(row.begin(), row.end(), 0.0);
+            for (int j = 0; j < D; ++j) {
+                const double a = w.wo[(size_t)i * D + j];
+                const float* q = w.out_proj + (size_t)j * D;
+                for (int c2 = 0; c2 < D; ++c2) row[c2] += a * (double)q[c2];
+            }
+            for (int c2 = 0; c2 < D; ++c2) wo[(size_t)i * D + c2] = (float)row[c2];
+        }
+        TRY(make_conv(L->qkv, D, 3 * D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, wq.data(), nullptr));
+        TRY(make_conv(L->wo, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, wo.data(), nullptr));
+    } else {
+        TRY(make_conv(L->qkv, D, 3 * D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.qkv, nullptr));
+        // MHA in_proj: three bias-free (D,D) projections of three different inputs = a grouped 1x1 conv
+        TRY(make_conv(L->in_proj, 3 * D, 3 * D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.in_proj, nullptr, 3));
+        TRY(make_conv(L->out_proj, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.out_proj, nullptr));
+        TRY(make_conv(L->wo, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.wo, nullptr));
+    }
     TRY(make_conv(L->conv1, D, F, c.ffn_k1, 1, (c.ffn_k1 - 1) / 2, 0, 1, PRE_NONE, 0.f, ACT_RELU, w.conv1_w, w.conv1_b));
     TRY(make_conv(L->conv2, F, D, c.ffn_k2, 1, (c.ffn_k2 - 1) / 2, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.conv2_w, w.conv2_b));
     TRY(upload(&L->an_w, w.attn_norm_w, D));
@@ -978,8 +1012,12 @@ static int layernorm(const float* x, const float* g, const float* b, float* y, i
 static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, float* x, const uint8_t* valid, int B, int T, hipStream_t s) {
     const int D = t->cfg.d_model, H = L->heads, hd = D / H;
     TRY(layernorm(x, L->an_w, L->an_b, w.n, B, D, T, 0, s));
-    TRY(conv_launch(L->qkv.get(), w.n, nullptr, w.qkv1, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
-    TRY(conv_launch(L->in_proj.get(), w.qkv1, nullptr, w.qkv2, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+    if (L->merged) {
+        TRY(conv_launch(L->qkv.get(), w.n, nullptr, w.qkv2, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+    } else {
+        TRY(conv_launch(L->qkv.get(), w.n, nullptr, w.qkv1, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+        TRY(conv_launch(L->in_proj.get(), w.qkv1, nullptr, w.qkv2, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+    }
     const long DT = (long)D * T;
     {   // scores[b,h][tq][tk] = sum_c (q[c][tq] * sqrt(1/hd)) * k[c][tk]
         BgemmParams p{};
@@ -1005,8 +1043,12 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
         hipLaunchKernelGGL(bgemm_mfma_kernel, dim3((T + 63) / 64, (hd + 63) / 64, B * H), dim3(256), 0, s, p);
         HIP_TRY(hipGetLastError());
     }
-    TRY(conv_launch(L->out_proj.get(), w.ctx, nullptr, w.o, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
-    TRY(conv_launch(L->wo.get(), w.o, x, w.h, B, T, EPI_STORE, 1.f, 0, 0, 0, s));          // h = x + attn
+    if (L->merged) {
+        TRY(conv_launch(L->wo.get(), w.ctx, x, w.h, B, T, EPI_STORE, 1.f, 0, 0, 0, s));        // h = x + attn
+    } else {
+        TRY(conv_launch(L->out_proj.get(), w.ctx, nullptr, w.o, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
+        TRY(conv_launch(L->wo.get(), w.o, x, w.h, B, T, EPI_STORE, 1.f, 0, 0, 0, s));          // h = x + attn
+    }
     TRY(layernorm(w.h, L->cn_w, L->cn_b, w.n, B, D, T, 0, s));
     TRY(conv_launch(L->conv1.get(), w.n, nullptr, w.f, B, T, EPI_STORE, 1.f, 0, 0, 0, s));  // relu fused
     TRY(conv_launch(L->conv2.get(), w.f, w.h, x, B, T, EPI_STORE, 1.f, 0, 0, 0, s));        // out = h + ffn
