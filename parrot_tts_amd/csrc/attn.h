@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_mfma.h"
+#include "kernels_misc.h"
 
 namespace parrot {
 
@@ -70,6 +71,131 @@ __global__ __launch_bounds__(256) void bgemm_mfma_kernel(const BgemmParams p) {
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m < p.M && n < p.N) C[(long)m * p.ldc + n] = acc[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused attention core for sequences of <= 256 steps: scores, key-padding softmax and context in ONE launch per
+// (batch, head, 64 queries) instead of bgemm -> softmax_mask -> bgemm with the (B, H, T, T) score tensor going
+// through HBM twice.  Same arithmetic as the three-kernel path, in the same order (v_mfma_f32_32x32x2_f32 over
+// ascending channel / key pairs; the softmax row reductions of softmax_mask_kernel), so the results are bit-identical:
+//   phase 1  S[tq][tk] = sum_c (alpha q[c][tq]) k[c][tk]  -> LDS, 64 x T            (32x32 tiles dealt round-robin to waves)
+//   softmax  P = softmax(S + key mask) per query row, in LDS                        (16 rows per wave)
+//   phase 2  ctx[c][tq] = sum_tk v[c][tk] P[tq][tk]                                 (wave w: channels 32w.., both query tiles)
+// q / k / v / ctx are channel-first (hd, T) slices of the (B, 3, D, T) projection buffer / (B, D, T) context buffer.
+struct AttnParams {
+    const float* qkv;      // (B, 3, D, T)
+    const uint8_t* valid;  // (B, T) 1 = real key
+    float* ctx;            // (B, D, T)
+    int T, H, D, hd;
+    float alpha;
+};
+constexpr int ATTN_TMAX = 256;
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
+    extern __shared__ float Ps[];  // [64][TP]
+    constexpr int KB = 8;          // MFMA k-steps per operand batch (operands are fetched a batch ahead)
+    const int T = p.T, ntile = (T + 31) / 32, TP = ntile * 32 + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
+    const int tq0 = blockIdx.x * 64;
+    const long DT = (long)p.D * T;
+    const float* __restrict__ q = p.qkv + (long)b * 3 * DT + (long)h * HD * T;
+    const float* __restrict__ k = q + DT;
+    const float* __restrict__ v = q + 2 * DT;
+
+    // ---- phase 1: 2 query tiles x ntile key tiles of 32x32, round-robin over the four waves ---------------------
+    for (int pair = wave; pair < 2 * ntile; pair += 4) {
+        const int mt = pair & 1, nt = pair >> 1;
+        const int tq = tq0 + mt * 32 + l31, tk = nt * 32 + l31;
+        const bool qok = tq < T, kok = tk < T;
+        const float* __restrict__ qp = q + (qok ? tq : 0) + (long)half * T;
+        const float* __restrict__ kp = k + (kok ? tk : 0) + (long)half * T;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float a[2][KB], bb[2][KB];
+        auto fetch = [&](int set, int c0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+                a[set][i] = qp[(long)(c0 + 2 * i) * T];
+                bb[set][i] = kp[(long)(c0 + 2 * i) * T];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int it = 0; it < HD / (2 * KB); ++it) {
+            if (it + 1 < HD / (2 * KB)) fetch((it + 1) & 1, (it + 1) * 2 * KB);
+#pragma unroll
+            for (int i = 0; i < KB; ++i)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qok ? a[it & 1][i] * p.alpha : 0.f, kok ? bb[it & 1][i] : 0.f, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ps[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TP + tk] = acc[r];
+    }
+    __syncthreads();
+
+    // ---- softmax over the keys, masked by key validity (as softmax_mask_kernel) -------------------------------
+    const uint8_t* __restrict__ kv = p.valid + (long)b * T;
+    for (int row = wave * 16; row < wave * 16 + 16; ++row) {
+        if (tq0 + row >= T) break;
+        float* sr = Ps + row * TP;
+        float mx = -INFINITY;
+        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, kv[t] ? sr[t] : -INFINITY);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const float e = kv[t] ? expf(sr[t] - mx) : 0.f;
+            sr[t] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        for (int t = lane; t < T; t += 64) sr[t] = sr[t] / sum;
+        for (int t = T + lane; t < ntile * 32; t += 64) sr[t] = 0.f;  // padded keys contribute nothing
+    }
+    __syncthreads();
+
+    // ---- phase 2: channel tiles of 32, both query tiles; keys in batches of 2*KB (the padded P columns are 0) -----
+    float* __restrict__ ctx = p.ctx + (long)b * DT + (long)h * HD * T;
+    const int nbatch = (T + 2 * KB - 1) / (2 * KB);
+    for (int ct = wave; ct < HD / 32; ct += 4) {
+        const float* __restrict__ vp = v + (long)(ct * 32 + l31) * T + half;
+        const float* __restrict__ p0 = Ps + l31 * TP + half;
+        const float* __restrict__ p1 = p0 + 32 * TP;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        float a[2][KB];
+        auto fetch = [&](int set, int t0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+                const int t = t0 + 2 * i;
+                a[set][i] = (t + half < T) ? vp[t] : 0.f;
+            }
+        };
+        fetch(0, 0);
+        for (int it = 0; it < nbatch; it += 2) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int t0 = (it + sub) * 2 * KB;
+                if (t0 < T) {
+                    fetch(sub ^ 1, t0 + 2 * KB);  // (past the end: zeros)
+#pragma unroll
+                    for (int i = 0; i < KB; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sub][i], p0[t0 + 2 * i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sub][i], p1[t0 + 2 * i], acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = (long)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * T;
+            if (tq0 + l31 < T) ctx[row + tq0 + l31] = acc0[r];
+            if (tq0 + 32 + l31 < T) ctx[row + tq0 + 32 + l31] = acc1[r];
+        }
     }
 }
 

@@ -245,17 +245,18 @@ __global__ __launch_bounds__(256) void duration_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // Length regulator + positional row (duration.py:6-24, parrot.py:106, data.py:8-20):
 // y[b, c, t] = (t < len_b ? enc[b, c, src(t)] : 0) + pe[L][c], src(t) = first s with cum[b,s] > t;
-// tgt_mask[b,t] = t <= len_b (Q2).   grid (ceil(L/256), B).  idx is recomputed per (b,t) once and
+// tgt_mask[b,t] = t <= len_b (Q2).   grid (ceil(L/64), B).  idx is recomputed per (b,t) once and
 // reused over channels.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ enc, const int32_t* __restrict__ cum,
                                                               const int32_t* __restrict__ out_len, const float* __restrict__ pe_row,
                                                               float* __restrict__ y, uint8_t* __restrict__ tgt_mask, int S, int L, int D) {
     const int b = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6;  // lane = frame, the four waves split the channels
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
     if (t >= L) return;
     const int len = out_len[b];
-    tgt_mask[(size_t)b * L + t] = (t <= len) ? 1 : 0;
+    if (wave == 0) tgt_mask[(size_t)b * L + t] = (t <= len) ? 1 : 0;
     int src = -1;
     if (t < len) {
         const int32_t* cb = cum + (size_t)b * S;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
     }
     const float* eb = enc + (size_t)b * D * S;
     float* yb = y + (size_t)b * D * L + t;
-    for (int c = 0; c < D; ++c) {
+    for (int c = wave; c < D; c += 4) {
         const float v = (src >= 0) ? eb[(size_t)c * S + src] : 0.0f;
         yb[(size_t)c * L] = pe_row[c] + v;
     }

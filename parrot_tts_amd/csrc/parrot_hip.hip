@@ -1019,6 +1019,22 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
         TRY(conv_launch(L->in_proj.get(), w.qkv1, nullptr, w.qkv2, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
     }
     const long DT = (long)D * T;
+    static const bool fuse_attn = [] { const char* e = getenv("PARROT_FUSED_ATTN"); return !e || atoi(e) != 0; }();
+    if (fuse_attn && T <= ATTN_TMAX && hd == 128) {  // scores, softmax and context in one launch (attn.h)
+        AttnParams p{};
+        p.qkv = w.qkv2; p.valid = valid; p.ctx = w.ctx;
+        p.T = T; p.H = H; p.D = D; p.hd = hd;
+        p.alpha = (float)std::sqrt(1.0 / (double)hd);
+        const size_t lds = (size_t)64 * (((T + 31) / 32) * 32 + 1) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((size_t)64 * (ATTN_TMAX + 1) * sizeof(float))));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_fused_kernel<128>, dim3((T + 63) / 64, B * H), dim3(256), lds, s, p);
+        HIP_TRY(hipGetLastError());
+    } else {
     {   // scores[b,h][tq][tk] = sum_c (q[c][tq] * sqrt(1/hd)) * k[c][tk]
         BgemmParams p{};
         p.A = w.qkv2; p.B = w.qkv2 + DT; p.C = w.scores;
@@ -1042,6 +1058,7 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
         p.alpha = 1.0f;
         hipLaunchKernelGGL(bgemm_mfma_kernel, dim3((T + 63) / 64, (hd + 63) / 64, B * H), dim3(256), 0, s, p);
         HIP_TRY(hipGetLastError());
+    }
     }
     if (L->merged) {
         TRY(conv_launch(L->wo.get(), w.ctx, x, w.h, B, T, EPI_STORE, 1.f, 0, 0, 0, s));        // h = x + attn
@@ -1108,7 +1125,7 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
     TteScratch w = tte_scratch(t, a, B, std::max(S, L), true);
     if (!sa.ok || !a.ok) return fail(PARROT_E_NOMEM, "tte_decode: state/workspace too small");
     const int D = c.d_model, V = c.n_codes;
-    hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, st.enc_out, st.cum, st.out_len,
+    hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, st.enc_out, st.cum, st.out_len,
                        t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D);
     HIP_TRY(hipGetLastError());
     for (auto& Ly : t->dec) TRY(fft_block(t, Ly.get(), w, w.x, tgt_mask, B, L, s));
