@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--tiles", type=str, default="-1,0,1,2,3")
     ap.add_argument("--layers", type=str, default="", help="comma separated layer names (default: all)")
     ap.add_argument("--precision", type=int, default=-1, help="-1 library default, 0 exact fp32 MFMA, 1 split-bf16")
+    ap.add_argument("--constant", action="store_true", help="all-ones inputs and weights (operand toggling / clock experiments)")
     a = ap.parse_args()
     dev = "cuda:0"
     want = set(a.layers.split(",")) if a.layers else None
@@ -40,6 +41,9 @@ def main():
         x = torch.randn(a.batch, cin, T, device=dev)
         res = torch.randn(a.batch, cout, T, device=dev)
         out = torch.empty(a.batch, cout, T, device=dev)
+        if a.constant:
+            w, b = torch.full_like(w, 0.01), torch.zeros_like(b)
+            x, res = torch.ones_like(x), torch.ones_like(res)
         for tile in [int(t) for t in a.tiles.split(",")]:
             try:
                 plan = ops.ConvPlan(w, b, dilation=dil, padding=dil * (k - 1) // 2, pre_act=1, pre_slope=0.1, tile_cfg=tile, precision=a.precision)
