@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def norm(name: str) -> str:
     name = name.replace(" ", "")
-    m = re.match(r"(conv_bf16x6_kernel<\d+,\d+,\d+,\d+,\d+),\d+>", name)
+    m = re.match(r"(conv_bf16x6_kernel<\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
     if m:
         return m.group(1) + ">"
     return re.sub(r"^(resblock_bf16x6_kernel)<\d+>$", r"\1", name)  # 32- and 64-channel instantiations share bench.py's row
