@@ -273,6 +273,44 @@ class CodeGenerator(nn.Module):
                                               ws.numel(), stream_ptr(dev)))
         return wav
 
+    # Receptive field of the whole generator, in units either side of an output frame (+-6378 output
+    # samples ~ +-20 units, perturb-one-unit probe): an interior chunk computed with this much context is exact.
+    RECEPTIVE_UNITS = 20
+
+    @torch.no_grad()
+    def stream(self, chunk_units: int = 256, halo_units: Optional[int] = None, unit_lens: Optional[torch.Tensor] = None, **kwargs):
+        """Chunk-streamed synthesis (BASELINE config 5, long-form utterances): yields ``(first_sample, wav_chunk)`` for
+        consecutive chunks of ``chunk_units`` units.  Each chunk is vocoded with ``halo_units`` (default: the receptive
+        field) of real context on both sides and only its own samples are kept, so the concatenation equals the
+        whole-utterance ``forward`` to fp32 round-off; at the true sequence edges the chunk contains the edge itself, i.e.
+        the per-layer zero padding is applied where the reference applies it.  First audio after one chunk instead of the
+        whole utterance; peak workspace is that of ``chunk_units + 2 * halo_units`` units."""
+        code = kwargs["code"]
+        if chunk_units <= 0:
+            raise ValueError("chunk_units must be positive")
+        halo = self.RECEPTIVE_UNITS if halo_units is None else int(halo_units)
+        U, hop = code.shape[1], self.upsample_factor
+        for start in range(0, U, chunk_units):
+            stop = min(U, start + chunk_units)
+            lo, hi = max(0, start - halo), min(U, stop + halo)
+            kw = dict(kwargs)
+            kw["code"] = code[:, lo:hi]
+            lens = None
+            if unit_lens is not None:
+                lens = torch.clamp(unit_lens.to(code.device, torch.int64) - lo, min=0, max=hi - lo)
+            wav = self.forward(unit_lens=lens, **kw)
+            yield start * hop, wav[:, :, (start - lo) * hop:(stop - lo) * hop]
+
+    @torch.no_grad()
+    def forward_chunked(self, chunk_units: int = 256, halo_units: Optional[int] = None, unit_lens: Optional[torch.Tensor] = None,
+                        **kwargs) -> torch.Tensor:
+        """``forward`` assembled from ``stream`` chunks: same result, bounded activation memory."""
+        code = kwargs["code"]
+        out = torch.empty((code.shape[0], 1, code.shape[1] * self.upsample_factor), dtype=torch.float32, device=code.device)
+        for first, wav in self.stream(chunk_units, halo_units, unit_lens=unit_lens, **kwargs):
+            out[:, :, first:first + wav.shape[-1]] = wav
+        return out
+
     def check_inputs(self) -> None:
         """Synchronise and raise IndexError if a unit / speaker id of an earlier forward was out of range
         (what nn.Embedding raises eagerly in the reference)."""

@@ -490,3 +490,33 @@ def test_vocoder_ragged_batch_rows_equal_single_utterance_runs(cfg_name, prec, f
     y_plain = gen(code=batch["code"].to(DEV), spkr=batch["spkr"].to(DEV)).cpu()
     n = lens[1]
     assert float((y_plain[1, :, : n * hop] - y[1, :, : n * hop]).abs().max()) > 1e-3
+
+
+def test_chunk_streamed_vocoder_equals_whole_utterance(prec):
+    """SURVEY section 4 item 6 / BASELINE config 5: U = 200 whole vs chunk-streamed (64-unit chunks, receptive-field
+    halo) on the full-size generator; also ragged rows and a chunk size that does not divide U.  Interior chunks see
+    +-20 units of real context, edge chunks contain the true edge, so the two must agree to fp32 round-off: 2.4e-7
+    measured with the exact kernels; in the split-bf16 mode a short last chunk runs other tile variants (different
+    summation order), which the network depth amplifies to <= 1e-5 -- the same class as the parity error itself."""
+    h = synth.default_voc_config()
+    vsd = synth.synth_voc_state_dict(h, seed=1234)
+    gen = _gen(h, vsd)
+    batch = synth.synth_voc_batch(2, 200, h, seed=5)
+    code, spkr = batch["code"].to(DEV), batch["spkr"].to(DEV)
+    whole = gen(code=code, spkr=spkr)
+    for chunk in (64, 77):
+        got = gen.forward_chunked(chunk_units=chunk, code=code, spkr=spkr)
+        err = float((got - whole).abs().max())
+        _report(test="voc_chunk_stream", chunk_units=chunk, precision=prec, max_abs_diff=err)
+        assert err <= (2e-6 if prec == "f32" else 2e-5)
+    firsts = [f for f, _ in gen.stream(64, code=code, spkr=spkr)]
+    assert firsts == [0, 64 * 320, 128 * 320, 192 * 320]
+    lens = torch.tensor([200, 131])
+    whole_r = gen(code=code, spkr=spkr, unit_lens=lens.to(DEV))
+    got_r = gen.forward_chunked(chunk_units=64, code=code, spkr=spkr, unit_lens=lens.to(DEV))
+    for b in range(2):
+        n = int(lens[b]) * 320
+        assert float((got_r[b, :, :n] - whole_r[b, :, :n]).abs().max()) <= (2e-6 if prec == "f32" else 2e-5)
+    # a halo shorter than the receptive field must NOT be exact (the test would otherwise prove nothing)
+    short = gen.forward_chunked(chunk_units=64, halo_units=2, code=code, spkr=spkr)
+    assert float((short - whole).abs().max()) > 1e-3
