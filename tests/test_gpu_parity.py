@@ -520,3 +520,40 @@ def test_chunk_streamed_vocoder_equals_whole_utterance(prec):
     # a halo shorter than the receptive field must NOT be exact (the test would otherwise prove nothing)
     short = gen.forward_chunked(chunk_units=64, halo_units=2, code=code, spkr=spkr)
     assert float((short - whole).abs().max()) > 1e-3
+
+
+def test_text_to_waveform_helper_matches_manual_pipeline(tmp_path):
+    """demo.ipynb cells 9-13 via parrot_tts_amd.text.synthesize_text: same ids as Parrot.infer on the hand-built batch,
+    and the per-speaker fan-out run as one vocoder batch equals the per-speaker runs; ids also match the CPU oracle."""
+    from parrot_tts_amd import text as T
+    cfg, h = synth.small_tte_config(), synth.small_voc_config()
+    symbols = ["क", "ख", "ग", " ", "ा", "ि", ".", "म", "न"]
+    toks = ["<pad>", "<sep>"] + ["sil" if s == " " else s for s in symbols]
+
+    class Tok:
+        pad_idx = 0
+        stoi = {s: i for i, s in enumerate(toks)}
+
+        def tokenize(self, seq):
+            return [self.stoi[s] for s in seq]
+
+    vocab = len(toks)
+    tsd = synth.synth_tte_state_dict(cfg, vocab, 2, seed=21, forced_duration=3)
+    for k in list(tsd):  # the small vocoder knows 100 units: keep the head inside that range
+        if k.endswith("head.weight") or k.endswith("head.bias"):
+            tsd[k] = tsd[k].clone()
+            tsd[k][100:] = -10.0 if k.endswith("bias") else 0.0
+    vsd = synth.synth_voc_state_dict(h, seed=22)
+    parrot = _parrot(cfg, vocab, 2, tsd, tmp_path)
+    gen = _gen(h, vsd)
+    units, wav = T.synthesize_text("का खिग! मन | ३", parrot, gen, Tok(), symbols, speaker=1, vocoder_speakers=(0, 3, 7))
+    chars = T.text_to_characters(T.indic_cleaners("का खिग! मन | ३"), symbols)
+    batch = T.characters_to_batch(Tok(), chars, speaker=1)
+    assert units == parrot.infer({k: v.to(DEV) for k, v in batch.items()})[0]
+    with torch.no_grad():
+        assert units == O.tte_infer(tsd, cfg, batch)[0]
+    assert wav.shape == (3, 1, len(units) * 320)
+    code = torch.tensor([units], device=DEV)
+    for i, s in enumerate((0, 3, 7)):
+        one = gen(code=code, spkr=torch.tensor([[s]], device=DEV))
+        assert float((one[0] - wav[i]).abs().max()) <= 2e-6

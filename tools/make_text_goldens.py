@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Golden vectors for the dependency-free text cleaners of the reference (utils/aligner/cleaners.py:120-233).
+
+The reference module imports `inflect` and `unidecode` at the top; neither is installed here and neither is used by
+`nonenglish_cleaners_no_transliteration`, `replace_devanagari_numbers`, `number_to_hindi`, `collapse_whitespace`.
+This script executes the reference file WITHOUT those two imports (and the `_inflect = ...` line) and records the
+outputs of the reference's own functions on a fixed list of inputs -> tests/golden/text_cleaners.json (data only).
+Run in the build container (needs /root/reference): python tools/make_text_goldens.py"""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/utils/aligner/cleaners.py"
+
+CASES = [
+    "इसके लिए संरक्षित खेती, मधुमक्खी पालन इत्यादि पर अगले पंचवर्षीय योजना में महत्त्व देना होगा",
+    "  कई   खाली \t जगह\nऔर नई पंक्ति  ",
+    "वर्ष २०२ में ४५ लोग, १०० रुपये और ९९९ किताबें | ० शून्य है",
+    "अंक 2024 और 15 हटते हैं; (कोष्ठक) [वर्ग] {धनु} <कोण> \"उद्धरण\" 'एकल' — डैश – छोटा … दीर्घ",
+    "प्रतिशत 50% + योग = बराबर ^ घात \\ उल्टा _ रेखा ` उच्चारण @ पर / भाग - घटा * गुणा : ; ! अंत",
+    "“घुमावदार” ‘उद्धरण’ ⇒ तीर",
+    "नियंत्रण\x92वर्ण\xadयहाँ\x10और\x13भी\x14हैं\x16तथा\x91अंत",
+    "mixed English text, with ASCII: kept as is? Yes.",
+    "२१ २५ ३० ४७ ५९ ६६ ७८ ८४ ९३ १०१ ११० २५० ३९९ ५०० ७४२ ९०९",
+    "",
+    "|||",
+    "संख्या १००० बहुत बड़ी",   # >= 1000: number_to_hindi falls through (returns None) and re.sub drops the match
+    "१२३४५",
+]
+NUMBERS = [0, 1, 7, 10, 11, 19, 20, 21, 35, 48, 50, 77, 99, 100, 101, 110, 119, 200, 342, 500, 999]
+
+
+def load_reference_functions():
+    src = open(REF, encoding="utf-8").read()
+    src = re.sub(r"^import inflect\s*$", "", src, flags=re.M)
+    src = re.sub(r"^from unidecode import unidecode\s*$", "", src, flags=re.M)
+    src = re.sub(r"^_inflect = inflect\.engine\(\)\s*$", "", src, flags=re.M)
+    ns = {}
+    exec(compile(src, REF, "exec"), ns)
+    return ns
+
+
+def main():
+    ns = load_reference_functions()
+    out = {
+        "generator": "tools/make_text_goldens.py (reference functions executed from " + REF + ")",
+        "nonenglish_cleaners_no_transliteration": [[c, ns["nonenglish_cleaners_no_transliteration"](c)] for c in CASES],
+        "replace_devanagari_numbers": [[c, ns["replace_devanagari_numbers"](c)] for c in CASES],
+        "collapse_whitespace": [[c, ns["collapse_whitespace"](c)] for c in CASES],
+        "number_to_hindi": [[n, ns["number_to_hindi"](n)] for n in NUMBERS],
+    }
+    path = os.path.join(ROOT, "tests", "golden", "text_cleaners.json")
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False, indent=1)
+    print("wrote", path, {k: (len(v) if isinstance(v, list) else v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()
