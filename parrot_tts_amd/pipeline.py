@@ -18,6 +18,8 @@ from .vocoder import CodeGenerator
 class SynthesisPipeline:
     def __init__(self, parrot: Parrot, generator: CodeGenerator):
         self.parrot, self.generator = parrot, generator
+        self._side: Optional[torch.cuda.Stream] = None
+        self._pending: Optional[dict] = None
 
     @torch.no_grad()
     def __call__(self, batch: Dict[str, torch.Tensor], spkr: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -35,3 +37,46 @@ class SynthesisPipeline:
         # each row is vocoded with its own sequence end, i.e. exactly as the reference would vocode that row's ids alone
         wav = self.generator(code=ids, spkr=spkr, unit_lens=emitted)
         return {"wav": wav, "n_samples": emitted * hop, "ids": ids, "tgt_mask": r["tgt_mask"], "lens": r["lens"]}
+
+    # ---- two-stage software pipeline across batches --------------------------------------------------------------
+    # The TTE is ~13 % of a step but made of small, latency-bound launches (64-512 workgroups, one host round trip for
+    # the expanded length); the vocoder is 100+ chip-filling launches.  `submit` runs the TTE of batch i on a side HIP
+    # stream while the vocoder of batch i-1 -- enqueued first, on the caller's stream -- owns the chip, so the TTE's
+    # bubbles are filled by vocoder workgroups.  Results come back one call late, in order; `flush` drains.
+    @torch.no_grad()
+    def submit(self, batch: Dict[str, torch.Tensor], spkr: Optional[torch.Tensor] = None) -> Optional[Dict[str, torch.Tensor]]:
+        """Enqueue the vocoder of the previously submitted batch, run this batch's TTE beside it, return the previous
+        batch's result (None on the first call).  Same kernels and results as ``__call__``."""
+        dev = batch["phones"].device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        inputs_ready = main.record_event()  # recorded BEFORE the previous vocoder is enqueued behind it
+        done = self._vocode_pending(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(inputs_ready)
+            r = self.parrot.infer_dense(batch)  # (its host sync for L waits on the side stream only)
+            ids = r["ids"]
+            if spkr is None and self.generator.multispkr:
+                spkr = batch["speaker"].reshape(-1, 1)
+            emitted = torch.clamp(r["lens"].to(torch.int64) + 1, max=ids.shape[1])
+            emitted_dev = emitted.to(dev, torch.int32)
+            self._pending = {"ids": ids, "spkr": spkr, "emitted": emitted, "emitted_dev": emitted_dev, "tgt_mask": r["tgt_mask"],
+                             "lens": r["lens"], "event": self._side.record_event()}
+        return done
+
+    @torch.no_grad()
+    def flush(self) -> Optional[Dict[str, torch.Tensor]]:
+        """Vocode the last submitted batch (on the current stream) and return its result."""
+        return self._vocode_pending(torch.cuda.current_stream()) if self._pending is not None else None
+
+    def _vocode_pending(self, main: "torch.cuda.Stream") -> Optional[Dict[str, torch.Tensor]]:
+        p, self._pending = self._pending, None
+        if p is None:
+            return None
+        main.wait_event(p["event"])
+        for t in (p["ids"], p["emitted_dev"], p["tgt_mask"]) + ((p["spkr"],) if p["spkr"] is not None else ()):
+            t.record_stream(main)  # allocated on the side stream, consumed here
+        wav = self.generator(code=p["ids"], spkr=p["spkr"], unit_lens=p["emitted_dev"])
+        return {"wav": wav, "n_samples": p["emitted"] * self.generator.upsample_factor, "ids": p["ids"], "tgt_mask": p["tgt_mask"],
+                "lens": p["lens"]}

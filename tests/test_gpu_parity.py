@@ -557,3 +557,37 @@ def test_text_to_waveform_helper_matches_manual_pipeline(tmp_path):
     for i, s in enumerate((0, 3, 7)):
         one = gen(code=code, spkr=torch.tensor([[s]], device=DEV))
         assert float((one[0] - wav[i]).abs().max()) <= 2e-6
+
+
+def test_pipelined_submit_equals_sequential_calls(tmp_path):
+    """SynthesisPipeline.submit / flush (TTE of batch i on a side stream beside the vocoder of batch i-1) returns, one call
+    late and in order, exactly what __call__ returns for each batch -- different shapes per batch on purpose."""
+    from parrot_tts_amd.pipeline import SynthesisPipeline
+    cfg, h = synth.small_tte_config(), synth.small_voc_config()
+    vocab, n_spk = 30, 2
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=31)
+    for k in list(tsd):
+        if k.endswith("head.weight") or k.endswith("head.bias"):
+            tsd[k] = tsd[k].clone()
+            tsd[k][100:] = -10.0 if k.endswith("bias") else 0.0
+    vsd = synth.synth_voc_state_dict(h, seed=32)
+    pipe = SynthesisPipeline(_parrot(cfg, vocab, n_spk, tsd, tmp_path), _gen(h, vsd))
+    batches = [{k: v.to(DEV) for k, v in synth.synth_tte_batch(B, S, vocab, n_spk, seed=40 + i, ragged=True).items()}
+               for i, (B, S) in enumerate([(3, 11), (2, 17), (4, 9), (3, 11)])]
+    want = []
+    for b in batches:
+        r = pipe(b)
+        want.append({k: r[k].clone() for k in ("wav", "ids", "n_samples")})
+    got = []
+    for b in batches:
+        out = pipe.submit(b)
+        if out is not None:
+            got.append(out)
+    got.append(pipe.flush())
+    assert pipe.flush() is None and len(got) == len(want)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g["ids"], w["ids"]) and torch.equal(g["n_samples"].cpu(), w["n_samples"].cpu())
+        for row in range(w["wav"].shape[0]):
+            n = int(w["n_samples"][row])
+            assert torch.equal(g["wav"][row, :, :n], w["wav"][row, :, :n])
