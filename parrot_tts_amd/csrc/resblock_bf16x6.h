@@ -283,6 +283,10 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
 //   A (weights)  : lane l = row l&15, k-group g = l>>4: channels 8(g&1)..+7 of tap 2*step + (g>>1); the host packs
 //                  [conv][step][piece][lane][8 bf16].
 //   B (operand)  : lane l = column l&15 (+ tap shift (g>>1)*dil), channels 8(g&1)..+7: one ds_read_b128 per piece.
+//                  The two channel octets of a column swap places on odd 4-column groups: a ds_read_b128 lane group
+//                  here is {8 columns of octet 0, the 8 columns 8 further on of octet 1}, which land on 16 distinct
+//                  16-byte bank slots only if the swap does NOT depend on bit 3 of the column (the (col >> 3) swap of
+//                  the 32-column layout cost 0.34 conflict cycles per busy cycle here).
 //   C/D          : column l&15, rows 4(l>>4) + r.
 // Per step the 12 tiles are walked in pairs (terms outer, the two tiles inner, so dependent MFMAs are one apart);
 // the next pair's fragments are fetched during the current pair's MFMAs.
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
                 }
                 split3_pk(v0, v1, q0[e], q1[e], q2[e]);
             }
-            char* dst = smem_raw + c * 32 + (((g4 >> 1) ^ ((c >> 3) & 1)) * 16) + 8 * (g4 & 1);
+            char* dst = smem_raw + c * 32 + (((g4 >> 1) ^ ((c >> 2) & 1)) * 16) + 8 * (g4 & 1);
             *reinterpret_cast<uint2*>(dst) = uint2{q0[0], q0[1]};
             *reinterpret_cast<uint2*>(dst + PIECE_BYTES) = uint2{q1[0], q1[1]};
             *reinterpret_cast<uint2*>(dst + 2 * PIECE_BYTES) = uint2{q2[0], q2[1]};
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int cc = min(max(col0 + (2 * pr + q) * 16 + shift, 0), W - 1);
-            const char* src = smem_raw + cc * 32 + (((g4 & 1) ^ ((cc >> 3) & 1)) * 16);
+            const char* src = smem_raw + cc * 32 + (((g4 & 1) ^ ((cc >> 2) & 1)) * 16);
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bb[q][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
