@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void bgemm_mfma_kernel(const BgemmParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // Fused attention core for sequences of <= 256 steps: scores, key-padding softmax and context in ONE launch per
-// (batch, head, 64 queries) instead of bgemm -> softmax_mask -> bgemm with the (B, H, T, T) score tensor going
+// (batch, head, QT queries) instead of bgemm -> softmax_mask -> bgemm with the (B, H, T, T) score tensor going
 // through HBM twice.  Same arithmetic as the three-kernel path, in the same order (v_mfma_f32_32x32x2_f32 over
 // ascending channel / key pairs; the softmax row reductions of softmax_mask_kernel), so the results are bit-identical:
 //   phase 1  S[tq][tk] = sum_c (alpha q[c][tq]) k[c][tk]  -> LDS, 64 x T            (32x32 tiles dealt round-robin to waves)
@@ -92,23 +92,24 @@ struct AttnParams {
 };
 constexpr int ATTN_TMAX = 256;
 
-template <int HD>
+template <int HD, int QT>
 __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
-    extern __shared__ float Ps[];  // [64][TP]
+    constexpr int MT = QT / 32;    // query tiles of 32 per workgroup (QT = 32: 33 KiB of LDS -> 4 workgroups per CU)
+    extern __shared__ float Ps[];  // [QT][TP]
     constexpr int KB = 8;          // MFMA k-steps per operand batch (operands are fetched a batch ahead)
     const int T = p.T, ntile = (T + 31) / 32, TP = ntile * 32 + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
-    const int tq0 = blockIdx.x * 64;
+    const int tq0 = blockIdx.x * QT;
     const long DT = (long)p.D * T;
     const float* __restrict__ q = p.qkv + (long)b * 3 * DT + (long)h * HD * T;
     const float* __restrict__ k = q + DT;
     const float* __restrict__ v = q + 2 * DT;
 
     // ---- phase 1: 2 query tiles x ntile key tiles of 32x32, round-robin over the four waves ---------------------
-    for (int pair = wave; pair < 2 * ntile; pair += 4) {
-        const int mt = pair & 1, nt = pair >> 1;
+    for (int pair = wave; pair < MT * ntile; pair += 4) {
+        const int mt = pair % MT, nt = pair / MT;
         const int tq = tq0 + mt * 32 + l31, tk = nt * 32 + l31;
         const bool qok = tq < T, kok = tk < T;
         const float* __restrict__ qp = q + (qok ? tq : 0) + (long)half * T;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
 
     // ---- softmax over the keys, masked by key validity (as softmax_mask_kernel) -------------------------------
     const uint8_t* __restrict__ kv = p.valid + (long)b * T;
-    for (int row = wave * 16; row < wave * 16 + 16; ++row) {
+    for (int row = wave * (QT / 4); row < (wave + 1) * (QT / 4); ++row) {
         if (tq0 + row >= T) break;
         float* sr = Ps + row * TP;
         float mx = -INFINITY;
@@ -163,10 +164,11 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
     for (int ct = wave; ct < HD / 32; ct += 4) {
         const float* __restrict__ vp = v + (long)(ct * 32 + l31) * T + half;
         const float* __restrict__ p0 = Ps + l31 * TP + half;
-        const float* __restrict__ p1 = p0 + 32 * TP;
-        f32x16 acc0, acc1;
+        f32x16 acc[MT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
         float a[2][KB];
         auto fetch = [&](int set, int t0) __attribute__((always_inline)) {
 #pragma unroll
@@ -183,18 +185,19 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
                 if (t0 < T) {
                     fetch(sub ^ 1, t0 + 2 * KB);  // (past the end: zeros)
 #pragma unroll
-                    for (int i = 0; i < KB; ++i) {
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sub][i], p0[t0 + 2 * i], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sub][i], p1[t0 + 2 * i], acc1, 0, 0, 0);
-                    }
+                    for (int i = 0; i < KB; ++i)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sub][i], p0[m * 32 * TP + t0 + 2 * i], acc[m], 0, 0, 0);
                 }
             }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long row = (long)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * T;
-            if (tq0 + l31 < T) ctx[row + tq0 + l31] = acc0[r];
-            if (tq0 + 32 + l31 < T) ctx[row + tq0 + 32 + l31] = acc1[r];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (tq0 + m * 32 + l31 < T) ctx[row + tq0 + m * 32 + l31] = acc[m][r];
         }
     }
 }

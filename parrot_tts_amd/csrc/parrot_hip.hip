@@ -1025,14 +1025,16 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
         p.qkv = w.qkv2; p.valid = valid; p.ctx = w.ctx;
         p.T = T; p.H = H; p.D = D; p.hd = hd;
         p.alpha = (float)std::sqrt(1.0 / (double)hd);
-        const size_t lds = (size_t)64 * (((T + 31) / 32) * 32 + 1) * sizeof(float);
+        static const int qt = [] { const char* e = getenv("PARROT_ATTN_QT"); return (e && atoi(e) == 64) ? 64 : 32; }();
+        const size_t lds = (size_t)qt * (((T + 31) / 32) * 32 + 1) * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)((size_t)64 * (ATTN_TMAX + 1) * sizeof(float))));
             attr_set = true;
         }
-        hipLaunchKernelGGL(attn_fused_kernel<128>, dim3((T + 63) / 64, B * H), dim3(256), lds, s, p);
+        if (qt == 64) hipLaunchKernelGGL((attn_fused_kernel<128, 64>), dim3((T + 63) / 64, B * H), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((attn_fused_kernel<128, 32>), dim3((T + 31) / 32, B * H), dim3(256), lds, s, p);
         HIP_TRY(hipGetLastError());
     } else {
     {   // scores[b,h][tq][tk] = sum_c (q[c][tq] * sqrt(1/hd)) * k[c][tk]
