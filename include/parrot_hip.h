@@ -144,6 +144,13 @@ size_t parrot_voc_workspace_bytes(const parrot_voc_t*, int32_t B, int32_t U);
  * receive copies of the intermediate activations (tests only); NULL in production.            */
 int parrot_voc_forward(parrot_voc_t*, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B, int32_t U,
                        float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream);
+/* CodeGenerator.forward with extra conditioning keywords (utils/vocoder/models.py:162-167: every keyword tensor other
+ * than code / spkr / f0 is upsampled to U frames and concatenated behind the embeddings).  `feats`: dense fp32
+ * (B, n_feat_channels, U), the caller's streams already upsampled and concatenated in keyword order; it fills input
+ * channels [embedding_dim * (1 + multispkr), model_in_dim).  NULL / 0 when the model has none. */
+int parrot_voc_forward_feats(parrot_voc_t*, const int64_t* code, const int64_t* spkr, const float* feats, int32_t n_feat_channels,
+                             const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out, float* const* stage_out, void* ws,
+                             size_t ws_bytes, void* stream);
 int parrot_voc_check(parrot_voc_t*, void* stream);
 /* wav (n) fp32 -> int16 as `(x*32768).astype('int16')` does (utils/vocoder/inference.py:71-73) */
 int parrot_wav_to_int16(const float* wav, int16_t* out, size_t n, void* stream);

@@ -242,9 +242,24 @@ def generator_forward(w, h, x, stages: Optional[dict] = None):
     return torch.tanh(x)
 
 
-def code_generator_forward(sd, h, code, spkr=None, stages: Optional[dict] = None):
+def upsample_condition(signal, max_frames: int):
+    """utils/vocoder/models.py:132-151 (`CodeGenerator._upsample`): a (B,C,T') / (B,C) / flat conditioning signal is
+    repeated max_frames // T' times per frame; a remainder raises like the reference."""
+    if signal.dim() == 2:
+        signal = signal.unsqueeze(2)
+    elif signal.dim() != 3:
+        signal = signal.view(-1, 1, 1)
+    bsz, ch, cond = signal.shape
+    rep = max_frames // cond
+    if (max_frames - cond * rep) // rep > 0:
+        raise NotImplementedError("Padding condition signal - misalignment between condition features.")
+    return signal.unsqueeze(3).repeat(1, 1, 1, rep).view(bsz, ch, max_frames)
+
+
+def code_generator_forward(sd, h, code, spkr=None, stages: Optional[dict] = None, feats: Optional[dict] = None):
     """utils/vocoder/models.py:153-169 (+ _upsample :132-151): unit embedding (B,U,E)->(B,E,U),
-    speaker embedding broadcast over time, channel concat, Generator.forward.
+    speaker embedding broadcast over time, channel concat, then every EXTRA keyword tensor of the call (``feats``, in
+    keyword order; the reference skips 'spkr', 'code' and 'f0', :162-167) upsampled and concatenated, Generator.forward.
     ``sd`` may carry weight_g/weight_v or plain weight."""
     w = fold_weight_norm(sd)
     x = F.embedding(code, w["dict.weight"]).transpose(1, 2)
@@ -253,6 +268,10 @@ def code_generator_forward(sd, h, code, spkr=None, stages: Optional[dict] = None
         bsz, ch, cond = s.shape
         s = s.unsqueeze(3).repeat(1, 1, 1, x.shape[-1] // cond).view(bsz, ch, x.shape[-1])
         x = torch.cat([x, s], dim=1)
+    for name, feat in (feats or {}).items():
+        if name in ("spkr", "code", "f0"):
+            continue
+        x = torch.cat([x, upsample_condition(feat, x.shape[-1])], dim=1)
     if stages is not None:
         stages["embed"] = x
     return generator_forward(w, h, x, stages)

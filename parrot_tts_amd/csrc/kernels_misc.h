@@ -14,8 +14,8 @@ namespace parrot {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __restrict__ code, const int64_t* __restrict__ spkr,
                                                         const float* __restrict__ dict, const float* __restrict__ spk_tab,
-                                                        float* __restrict__ x, int U, int E, int C, int n_emb, int n_spk,
-                                                        int* __restrict__ err) {
+                                                        float* __restrict__ x, int U, int E, int C, int Cx, int n_emb, int n_spk,
+                                                        int* __restrict__ err) {  // C embedding channels of the Cx input channels
     __shared__ float tile[64][65];
     const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 rows of 64
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __restric
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
         const int c = c0 + r, t = t0 + tx;
-        if (c < C && t < U) x[((size_t)b * C + c) * U + t] = tile[tx][r];
+        if (c < C && t < U) x[((size_t)b * Cx + c) * U + t] = tile[tx][r];
     }
 }
 

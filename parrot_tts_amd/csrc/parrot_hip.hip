@@ -516,7 +516,8 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
         cfg->n_dil <= 0 || cfg->n_dil > PARROT_MAX_DIL || (cfg->resblock_type != 1 && cfg->resblock_type != 2))
         return fail(PARROT_E_INVALID, "voc_create: bad config");
     const int in_dim = cfg->embedding_dim * (cfg->multispkr ? 2 : 1);
-    if (in_dim != cfg->model_in_dim) return fail(PARROT_E_UNSUPPORTED, "voc_create: model_in_dim must equal embedding_dim * (1 + multispkr) (no f0 / extra feature streams)");
+    // model_in_dim - in_dim input channels come from the caller's extra conditioning streams (parrot_voc_forward_feats)
+    if (cfg->model_in_dim < in_dim) return fail(PARROT_E_INVALID, "voc_create: model_in_dim smaller than embedding_dim * (1 + multispkr)");
     if ((cfg->upsample_initial_channel >> cfg->n_stages) < 1) return fail(PARROT_E_INVALID, "voc_create: too many stages for upsample_initial_channel");
     const int per_rb = (cfg->resblock_type == 1 ? 2 : 1) * cfg->n_dil;
     if (w->n_rb != cfg->n_stages * cfg->n_kernels * per_rb) return fail(PARROT_E_INVALID, "voc_create: wrong number of resblock convs");
@@ -756,7 +757,18 @@ extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, i
 
 extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
                                   int32_t U, float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
+    return parrot_voc_forward_feats(v, code, spkr, nullptr, 0, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+}
+
+extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const float* feats,
+                                        int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
+                                        float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
     if (!v || !code || !wav_out || !ws) return fail(PARROT_E_INVALID, "voc_forward: null argument");
+    {
+        const int base = v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1);
+        if (n_feat_channels != v->cfg.model_in_dim - base || (n_feat_channels > 0 && !feats))
+            return fail(PARROT_E_INVALID, "voc_forward: extra feature channels must fill model_in_dim - embedding_dim * (1 + multispkr)");
+    }
     if (B <= 0 || U <= 0) return fail(PARROT_E_INVALID, "voc_forward: empty batch");
     if (v->cfg.multispkr && !spkr) return fail(PARROT_E_INVALID, "voc_forward: multispkr model needs spkr ids");
     hipStream_t s = (hipStream_t)stream;
@@ -769,10 +781,15 @@ extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const in
     if (!a.ok) return fail(PARROT_E_NOMEM, "voc_forward: workspace too small");
 
     {
-        dim3 grid((U + 63) / 64, (c.model_in_dim + 63) / 64, B);
+        const int base = c.embedding_dim * (c.multispkr ? 2 : 1);
+        dim3 grid((U + 63) / 64, (base + 63) / 64, B);
         hipLaunchKernelGGL(voc_embed_kernel, grid, dim3(256), 0, s, code, spkr, v->dict, v->spkr, x0, U, c.embedding_dim,
-                           c.model_in_dim, c.num_embeddings, c.n_spkr, v->err);
+                           base, c.model_in_dim, c.num_embeddings, c.n_spkr, v->err);
         HIP_TRY(hipGetLastError());
+        if (n_feat_channels > 0)  // extra conditioning streams (already upsampled to U frames) behind the embeddings
+            HIP_TRY(hipMemcpy2DAsync(x0 + (size_t)base * U, (size_t)c.model_in_dim * U * sizeof(float), feats,
+                                     (size_t)n_feat_channels * U * sizeof(float), (size_t)n_feat_channels * U * sizeof(float), B,
+                                     hipMemcpyDeviceToDevice, s));
     }
     auto snap = [&](int idx, const float* src, size_t n) -> int {
         if (stage_out && stage_out[idx]) HIP_TRY(hipMemcpyAsync(stage_out[idx], src, n * sizeof(float), hipMemcpyDeviceToDevice, s));

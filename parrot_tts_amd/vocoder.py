@@ -111,8 +111,7 @@ class CodeGenerator(nn.Module):
         self._n_emb = int(get("num_embeddings"))
         self.f0 = get("f0", None)
         self.multispkr = get("multispkr", None)
-        if self.f0:
-            raise NotImplementedError("f0-conditioned generators are not part of the Parrot-TTS synthesis path")
+        # (the reference stores h.f0 and never reads it again: forward() skips the `f0` keyword, models.py:163-164)
         n_dil = {len(d) for d in self._rb_d}
         if len(n_dil) != 1 or len(self._rb_d) != len(self._rb_k):
             raise NotImplementedError("resblock_dilation_sizes must give the same number of dilations per kernel size")
@@ -173,9 +172,8 @@ class CodeGenerator(nn.Module):
 
     # ---- HIP handle ---------------------------------------------------------------------------
     def _build(self, device):
-        if self._in_dim != self._emb_dim * (2 if self.multispkr else 1):
-            raise NotImplementedError("model_in_dim must equal embedding_dim * (1 + multispkr): extra feature streams "
-                                      "(reference models.py:162-167) are not on the synthesis path")
+        if self._in_dim < self._emb_dim * (2 if self.multispkr else 1):
+            raise ValueError("model_in_dim is smaller than embedding_dim * (1 + multispkr)")
         cfg = _lib.VocCfg()
         cfg.num_embeddings, cfg.embedding_dim = self._n_emb, self._emb_dim
         cfg.multispkr, cfg.n_spkr = int(bool(self.multispkr)), 10
@@ -227,9 +225,6 @@ class CodeGenerator(nn.Module):
         """``generator(code=..., spkr=...)`` as in the reference.  ``unit_lens`` (B,) int: real units per row of a padded
         (ragged) batch -- every layer then zero-pads at each row's own end, so ``wav[b, :, :unit_lens[b]*hop]`` equals the
         reference run of that utterance alone (the reference vocoder driver is B=1 only)."""
-        extra = [k for k in kwargs if k not in ("code", "spkr", "f0")]
-        if extra or kwargs.get("f0") is not None:
-            raise NotImplementedError(f"extra conditioning features {extra or ['f0']} are not on the synthesis path")
         code = kwargs["code"]
         require_cuda(code, "code")
         if code.dim() != 2 or code.dtype != torch.int64:
@@ -250,6 +245,15 @@ class CodeGenerator(nn.Module):
             lens32 = unit_lens.to(dev, torch.int32).contiguous()
             if lens32.numel() != B:
                 raise ValueError("unit_lens must have one entry per batch row")
+        # extra conditioning keywords (models.py:162-167): everything but code / spkr / f0 (f0 is skipped by the reference
+        # too) is upsampled to U frames and concatenated, in keyword order, behind the embeddings
+        feats, n_feat = None, 0
+        extra = [self._upsample(v.to(dev, torch.float32), U) for k, v in kwargs.items() if k not in ("code", "spkr", "f0")]
+        if extra:
+            feats = torch.cat(extra, dim=1).contiguous()
+            if feats.shape[0] != B:
+                raise ValueError("conditioning features must have one row per batch element")
+            n_feat = feats.shape[1]
         lib = _lib.lib()
         key = (B, U)
         if key not in self._ws:
@@ -269,8 +273,8 @@ class CodeGenerator(nn.Module):
             stage_ptrs = (C.c_void_p * len(bufs))(*[C.c_void_p(b.data_ptr()) for b in bufs])
             stages.update(dict(zip(names, bufs)))
         with torch.cuda.device(dev):
-            _lib.check(lib.parrot_voc_forward(self._handle, dptr(code), dptr(spkr), dptr(lens32), B, U, dptr(wav), stage_ptrs, dptr(ws),
-                                              ws.numel(), stream_ptr(dev)))
+            _lib.check(lib.parrot_voc_forward_feats(self._handle, dptr(code), dptr(spkr), dptr(feats), n_feat, dptr(lens32), B, U,
+                                                    dptr(wav), stage_ptrs, dptr(ws), ws.numel(), stream_ptr(dev)))
         return wav
 
     # Receptive field of the whole generator, in units either side of an output frame (+-6378 output
@@ -310,6 +314,23 @@ class CodeGenerator(nn.Module):
         for first, wav in self.stream(chunk_units, halo_units, unit_lens=unit_lens, **kwargs):
             out[:, :, first:first + wav.shape[-1]] = wav
         return out
+
+    @staticmethod
+    def _upsample(signal: torch.Tensor, max_frames: int) -> torch.Tensor:
+        """`CodeGenerator._upsample` (models.py:132-151): (B,C,T') / (B,C) / flat signal -> (B,C,max_frames) by repeating each
+        frame max_frames // T' times; a remainder raises NotImplementedError like the reference."""
+        if signal.dim() == 2:
+            signal = signal.unsqueeze(2)
+        elif signal.dim() != 3:
+            signal = signal.reshape(-1, 1, 1)
+        cond = signal.shape[2]
+        rep = max_frames // cond if cond else 0
+        if rep == 0 or (max_frames - cond * rep) // rep > 0:
+            raise NotImplementedError("Padding condition signal - misalignment between condition features.")
+        if cond * rep != max_frames:  # the reference gets past its remainder check here and dies in .view()
+            raise RuntimeError(f"shape '[{signal.shape[0]}, {signal.shape[1]}, {max_frames}]' is invalid for input of size "
+                               f"{signal.shape[0] * signal.shape[1] * cond * rep}")
+        return signal.repeat_interleave(rep, dim=2)
 
     def check_inputs(self) -> None:
         """Synchronise and raise IndexError if a unit / speaker id of an earlier forward was out of range

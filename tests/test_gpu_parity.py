@@ -591,3 +591,28 @@ def test_pipelined_submit_equals_sequential_calls(tmp_path):
         for row in range(w["wav"].shape[0]):
             n = int(w["n_samples"][row])
             assert torch.equal(g["wav"][row, :, :n], w["wav"][row, :, :n])
+
+
+def test_vocoder_extra_conditioning_streams(golden_dir, prec):
+    """Extra keyword tensors of CodeGenerator.forward (models.py:162-167) through parrot_voc_forward_feats, against the
+    reference golden; `f0` is ignored as in the reference; a stream that does not tile U raises like the reference."""
+    z = np.load(os.path.join(golden_dir, "voc_small_feats.npz"))
+    m = json.loads(str(z["meta"]))
+    h = synth.clone_config(synth.small_voc_config())
+    h["model_in_dim"] += m["extra_channels"]
+    sd = synth.synth_voc_state_dict(h, seed=m["seed_w"])
+    assert synth.state_digest(sd) == str(z["digest"])
+    g = _gen(h, sd)
+    kw = dict(code=torch.from_numpy(z["code"]).to(DEV), spkr=torch.from_numpy(z["spkr"]).to(DEV), f0=torch.from_numpy(z["f0"]).to(DEV),
+              energy=torch.from_numpy(z["energy"]).to(DEV), style=torch.from_numpy(z["style"]).to(DEV))
+    y = g(**kw).cpu().numpy()
+    err = float(np.abs(y - z["wav"]).max())
+    _report(test="voc_extra_feats", precision=prec, max_abs_err=err)
+    assert err <= 5e-5
+    with pytest.raises(NotImplementedError):  # 20 = 2 * 7 + 6 (models.py:146-148)
+        g(code=kw["code"], spkr=kw["spkr"], energy=torch.zeros(2, 2, 7, device=DEV), style=kw["style"])
+    with pytest.raises(RuntimeError):         # 20 = 6 * 3 + 2: the reference fails in .view() there
+        g(code=kw["code"], spkr=kw["spkr"], energy=torch.zeros(2, 2, 3, device=DEV), style=kw["style"])
+    with pytest.raises(Exception):  # the model expects 3 extra channels
+        g(code=kw["code"], spkr=kw["spkr"])
+    g.check_inputs()

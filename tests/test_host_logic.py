@@ -119,8 +119,7 @@ def test_generator_state_dict_layouts(tmp_path):
     torch.save({"generator": sd}, tmp_path / "g_00000010")
     torch.save({"generator": sd}, tmp_path / "g_00000002")
     assert checkpoint.scan_checkpoint(str(tmp_path), "g_").endswith("g_00000010")
-    with pytest.raises(NotImplementedError):
-        CodeGenerator(AttrDict(dict(h, f0=True)))
+    assert CodeGenerator(AttrDict(dict(h, f0=True))).f0 is True  # stored and, like the reference's forward, never used
 
 
 def test_no_cpu_fallback_and_oracle_is_not_imported_by_the_product(tmp_path):

@@ -110,3 +110,21 @@ def test_vocoder_oracle_matches_reference(golden_dir, name):
             assert np.array_equal(st[k[6:]].numpy(), z[k]), k
     if "wav_fp64" in z.files:  # the reference's own fp32 round-off at realistic scale
         assert np.abs(z["wav"] - z["wav_fp64"]).max() < 5e-5
+
+
+def test_vocoder_extra_conditioning_streams_match_reference(golden_dir):
+    """CodeGenerator.forward with extra keyword tensors (models.py:162-167): oracle == reference golden, bit for bit."""
+    z = np.load(os.path.join(golden_dir, "voc_small_feats.npz"))
+    m = json.loads(str(z["meta"]))
+    h = synth.clone_config(synth.small_voc_config())
+    h["model_in_dim"] += m["extra_channels"]
+    sd = synth.synth_voc_state_dict(h, seed=m["seed_w"])
+    assert synth.state_digest(sd) == str(z["digest"])
+    feats = {"f0": torch.from_numpy(z["f0"]), "energy": torch.from_numpy(z["energy"]), "style": torch.from_numpy(z["style"])}
+    with torch.no_grad():
+        y = O.code_generator_forward(sd, h, torch.from_numpy(z["code"]), torch.from_numpy(z["spkr"]), feats=feats)
+    assert np.array_equal(y.numpy(), z["wav"])
+    with pytest.raises(NotImplementedError):  # 20 = 2 * 7 + 6: the remainder check of models.py:146-148 fires
+        O.upsample_condition(torch.zeros(2, 1, 7), 20)
+    with pytest.raises(RuntimeError):         # 20 = 6 * 3 + 2: passes that check and fails in .view(), as the reference does
+        O.upsample_condition(torch.zeros(2, 1, 3), 20)

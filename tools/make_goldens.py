@@ -196,7 +196,32 @@ def voc_case(name, h, B, U, seed_w, seed_in, scale, with_stages=False, fp64=Fals
                         wav_int16=O.to_int16(y_wn.squeeze(1)), **extra)
 
 
+def voc_feats_case(name="voc_small_feats"):
+    """CodeGenerator.forward with extra conditioning keywords (models.py:162-167): a (B,2,U/2) stream and a (B,1) global
+    value are upsampled and concatenated after the unit / speaker embeddings; `f0` is passed and must be ignored."""
+    h = synth.clone_config(synth.small_voc_config())
+    h["model_in_dim"] = h["model_in_dim"] + 3
+    B, U = 2, 20
+    sd = synth.synth_voc_state_dict(h, seed=13)
+    batch = synth.synth_voc_batch(B, U, h, seed=8)
+    g = torch.Generator().manual_seed(99)
+    energy = torch.randn(B, 2, U // 2, generator=g)
+    style = torch.randn(B, 1, generator=g)
+    f0 = torch.randn(B, 1, U, generator=g)
+    ref = build_ref_codegen(h, sd, remove_wn=False)
+    with torch.no_grad():
+        y = ref(code=batch["code"], spkr=batch["spkr"], f0=f0, energy=energy, style=style)
+        y_o = O.code_generator_forward(sd, h, batch["code"], batch["spkr"], feats={"f0": f0, "energy": energy, "style": style})
+    print(f"[{name}] |y|max {float(y.abs().max()):.3f} oracle-vs-ref {maxdiff(y_o, y):.3g}")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), digest=np.array(synth.state_digest(sd)),
+                        meta=np.array(json.dumps(dict(B=B, U=U, seed_w=13, seed_in=8, extra_channels=3))),
+                        code=batch["code"].numpy(), spkr=batch["spkr"].numpy(), energy=energy.numpy(), style=style.numpy(),
+                        f0=f0.numpy(), wav=y.numpy())
+
+
 def main():
+    if "--only-feats" in sys.argv:  # added later: leaves the other (bit-pinned) goldens untouched
+        return voc_feats_case()
     full_t, small_t = synth.default_tte_config(), synth.small_tte_config()
     # 1. TTE-small: ragged pads, 2 speakers (full-size model)
     tte_case("tte_full_ragged", full_t, vocab=60, n_spk=2, B=3, S=23, seed_w=0, seed_in=1, ragged=True)
@@ -222,6 +247,7 @@ def main():
     rb2["resblock"] = "2"
     rb2["resblock_dilation_sizes"] = [[1, 3], [1, 3], [1, 3]]
     voc_case("voc_small_resblock2", rb2, B=2, U=9, seed_w=11, seed_in=7, scale=1.0)
+    voc_feats_case()
 
 
 if __name__ == "__main__":
