@@ -616,3 +616,25 @@ def test_vocoder_extra_conditioning_streams(golden_dir, prec):
     with pytest.raises(Exception):  # the model expects 3 extra channels
         g(code=kw["code"], spkr=kw["spkr"])
     g.check_inputs()
+
+
+def test_full_vocoder_on_tiny_sequences(prec):
+    """Sequences far shorter than any tile / fused window (1-7 units = 320-2240 samples) and ragged rows down to one unit,
+    on the full-size generator: every layer's window, halo and edge handling with T < W, against the oracle."""
+    h = synth.default_voc_config()
+    vsd = synth.synth_voc_state_dict(h, seed=1234)
+    gen = _gen(h, vsd)
+    for B, U in [(1, 1), (2, 2), (1, 3), (3, 5)]:
+        b = synth.synth_voc_batch(B, U, h, seed=U)
+        with torch.no_grad():
+            ref = O.code_generator_forward(vsd, h, b["code"], b["spkr"])
+        y = gen(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV)).cpu()
+        assert float((y - ref).abs().max()) <= 5e-5
+    b = synth.synth_voc_batch(3, 9, h, seed=3)
+    lens = torch.tensor([9, 1, 4])
+    y = gen(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV), unit_lens=lens.to(DEV)).cpu()
+    for r in range(3):
+        n = int(lens[r])
+        with torch.no_grad():
+            ref = O.code_generator_forward(vsd, h, b["code"][r:r + 1, :n], b["spkr"][r:r + 1])
+        assert float((y[r:r + 1, :, :n * 320] - ref).abs().max()) <= 5e-5
