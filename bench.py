@@ -139,16 +139,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run(precision, steps, warmup, overlap_steps=False):
+    def run(precision, steps, warmup, overlap_steps=False, workload=None, B=B):
         """Build both models under `precision`, then W untimed + K timed steps.  Returns (max-over-ranks seconds,
-        per-kernel profile rows, last gathered waveform batch on rank 0, model pieces for the CPU baseline)."""
+        per-kernel profile rows, samples per step over all ranks, model pieces for the CPU baseline)."""
+        workload = workload or a.workload
         ops.set_default_precision(ops.PREC_BF16X6 if precision == "bf16x6" else ops.PREC_F32)
         cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
         pipe = SynthesisPipeline(parrot, gen)
         batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(B, S, vocab, n_spk, seed=rank).items()}
         vb = {k: v.to(dev) for k, v in synth.synth_voc_batch(B, 4 * S, h, seed=rank).items()}
 
-        overlap = overlap_steps and a.workload == "full"
+        overlap = overlap_steps and workload == "full"
 
         def finish(out):
             if out is None:
@@ -158,7 +159,7 @@ def main():
         def step():
             if overlap:  # TTE of this batch beside the vocoder of the previous one; results one call late
                 return finish(pipe.submit(batch))
-            wav = pipe(batch)["wav"] if a.workload == "full" else gen(code=vb["code"], spkr=vb["spkr"])
+            wav = pipe(batch)["wav"] if workload == "full" else gen(code=vb["code"], spkr=vb["spkr"])
             return pdist.gather_waveforms(wav, dst=0) if world > 1 else wav
 
         def drain():  # every submitted batch is finished inside the region that submitted it
@@ -236,6 +237,12 @@ def main():
             "value": n1 / (ms1 / 1e3), "unit": "samples/s", "ms_per_step": ms1, "steps": a.steps,
             "schedule": "one batch at a time" if a.overlap else "TTE of batch i on a side HIP stream beside the vocoder of batch i-1 "
                         "(SynthesisPipeline.submit / flush); all submitted batches finish inside the timed region"}
+    if world == 1 and a.workload == "full" and not a.no_alt:
+        # BASELINE.json configs[1]: HiFi-GAN generator only, batch 32 x 256 units
+        e3, _, n3, _ = run(a.precision, a.steps, max(a.warmup, 3), workload="vocoder", B=32)
+        ms3 = e3 / a.steps * 1e3
+        res["vocoder_only_b32"] = {"value": n3 / (ms3 / 1e3), "unit": "samples/s", "ms_per_step": ms3, "steps": a.steps,
+                                   "workload": "HiFi-GAN generator only, batch 32 x %d units (BASELINE configs[1])" % (4 * S)}
     if world == 1 and a.precision == "bf16x6" and not a.no_alt:
         # the same workload with every product on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32), for reference
         e2, rows2, n2, _ = run("f32", min(a.steps, 5), 1)
