@@ -83,8 +83,11 @@ class ConvPlan:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            _lib.lib().parrot_conv_destroy(h)
+        if h and _lib is not None:  # (module globals are already torn down at interpreter exit)
+            try:
+                _lib.lib().parrot_conv_destroy(h)
+            except Exception:
+                pass
 
 
 def wav_to_int16(wav: torch.Tensor) -> torch.Tensor:
