@@ -84,36 +84,37 @@ __global__ void add_channel_vec_kernel(float* __restrict__ x, const int64_t* __r
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over channels of a channel-first tensor (fft.py:91-92,98-99; duration.py:32,36):
 // biased variance, eps inside the sqrt, affine.  Optional ReLU on the input (duration predictor:
-// Conv -> ReLU -> LayerNorm).  One block = 64 consecutive t (one per lane) x 4 waves striding the
-// channels; two passes over L2-resident data (mean, then centred variance) like torch's CPU kernel
-// in exact arithmetic order-insensitivity terms; cross-wave combine through LDS.
+// Conv -> ReLU -> LayerNorm).  Two passes (mean, then centred variance), cross-wave combine through LDS.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ y, int C, int T,
-                                                           float eps, int relu_in) {
-    // lane = time step, the four waves split the channels (c = wave, wave + 4, ...); for C <= 256 a thread's
-    // channel values stay in registers (one global read), wider layers re-read them per pass
-    __shared__ float red[4][64];
-    constexpr int MAXV = 64;
+// NW waves per block split the channels (c = wave, wave + NW, ...); lane = time step, so every load / store is a
+// coalesced 256-byte row segment.  For C <= NW * 16 a thread's channel values stay in registers (one global read);
+// wider layers re-read them per pass.  (NW = 16: 16 waves per (batch row, 64 steps) keep a CU busy where 4 left it
+// latency-bound.)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void layernorm_cf_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y, int C, int T,
+                                                                float eps, int relu_in) {
+    __shared__ float red[NW][64];
+    constexpr int MAXV = 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane, b = blockIdx.y;
     const bool ok = t < T;
     const float* xb = x + (size_t)b * C * T + (ok ? t : 0);
-    const bool in_regs = C <= 4 * MAXV;
+    const bool in_regs = C <= NW * MAXV;
     float vals[MAXV];
     float s = 0.f;
     if (in_regs) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const int c = wave + 4 * i;
+            const int c = wave + NW * i;
             float v = (c < C) ? xb[(size_t)c * T] : 0.f;
             if (relu_in) v = v > 0.f ? v : 0.f;
             vals[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) s += (wave + 4 * i < C) ? vals[i] : 0.f;
+        for (int i = 0; i < MAXV; ++i) s += (wave + NW * i < C) ? vals[i] : 0.f;
     } else {
-        for (int c = wave; c < C; c += 4) {
+        for (int c = wave; c < C; c += NW) {
             float v = xb[(size_t)c * T];
             if (relu_in) v = v > 0.f ? v : 0.f;
             s += v;
@@ -121,17 +122,20 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
     }
     red[wave][lane] = s;
     __syncthreads();
-    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w][lane];
+    const float mean = tot / (float)C;
     __syncthreads();
     float q = 0.f;
     if (in_regs) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const float d = vals[i] - mean;
-            q += (wave + 4 * i < C) ? d * d : 0.f;
+            q += (wave + NW * i < C) ? d * d : 0.f;
         }
     } else {
-        for (int c = wave; c < C; c += 4) {
+        for (int c = wave; c < C; c += NW) {
             float v = xb[(size_t)c * T];
             if (relu_in) v = v > 0.f ? v : 0.f;
             const float d = v - mean;
@@ -140,18 +144,21 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
     }
     red[wave][lane] = q;
     __syncthreads();
-    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    float qt = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) qt += red[w][lane];
+    const float var = qt / (float)C;
     const float rstd = 1.0f / sqrtf(var + eps);
     if (ok) {
         float* yb = y + (size_t)b * C * T + t;
         if (in_regs) {
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
-                const int c = wave + 4 * i;
+                const int c = wave + NW * i;
                 if (c < C) yb[(size_t)c * T] = (vals[i] - mean) * rstd * gamma[c] + beta[c];
             }
         } else {
-            for (int c = wave; c < C; c += 4) {
+            for (int c = wave; c < C; c += NW) {
                 float v = xb[(size_t)c * T];
                 if (relu_in) v = v > 0.f ? v : 0.f;
                 yb[(size_t)c * T] = (v - mean) * rstd * gamma[c] + beta[c];

@@ -1020,7 +1020,7 @@ extern "C" size_t parrot_tte_workspace_bytes(const parrot_tte_t* t, int32_t B, i
 }
 
 static int layernorm(const float* x, const float* g, const float* b, float* y, int B, int C, int T, int relu_in, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_cf_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, g, b, y, C, T, 1e-5f, relu_in);
+    hipLaunchKernelGGL(layernorm_cf_kernel<16>, dim3((T + 63) / 64, B), dim3(16 * 64), 0, s, x, g, b, y, C, T, 1e-5f, relu_in);
     HIP_TRY(hipGetLastError());
     return PARROT_OK;
 }
