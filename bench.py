@@ -40,7 +40,7 @@ TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>"
               "conv_mfma_kernel<2,2,2,2,32,3>", "conv_mfma_kernel<2,2,2,1,16,3>", "conv_mfma_kernel<1,4,1,2,16,4>",
               "conv_mfma16_kernel<8,2>", "conv_bf16x6_kernel<2,2,2,2,2>", "conv_bf16x6_kernel<1,4,2,2,2>", "resblock_fused16_kernel",
               "conv_bf16x6_kernel<2,2,2,1,3>", "conv_bf16x6_kernel<1,4,1,4,2>", "resblock_bf16x6_kernel", "resblock16_bf16x6_kernel",
-              "conv1_valu_kernel<7>", "convt_valu_kernel<16,4,2,1>"]
+              "conv1_valu_kernel", "convt_valu_kernel<16,4,2,1>"]
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the split scheme spends 6 bf16 MFMA FMAs per algorithmic fp32 FMA
 
 

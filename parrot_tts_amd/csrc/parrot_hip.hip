@@ -332,7 +332,9 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
     // the two narrowest vocoder layers stream through plain fp32 FMA kernels (conv_valu.h) in either precision mode
     const bool slope01 = d->pre_act != PRE_LRELU || (d->pre_slope >= 0.f && d->pre_slope <= 1.f);
     if (d->tile_cfg < 0 && groups == 1 && slope01 && d->dilation == 1 && valu_kernels_enabled()) {
-        if (!d->transposed && d->c_out == 1 && d->k == 7 && d->padding == 3 && (d->act == ACT_NONE || d->act == ACT_TANH)) c->valu_kind = 1;
+        if (!d->transposed && d->c_out == 1 && ((d->k == 7 && d->padding == 3) || (d->k == 1 && d->padding == 0)) &&
+            (d->act == ACT_NONE || d->act == ACT_TANH))
+            c->valu_kind = 1;  // conv_post; the duration predictor's Linear(256 -> 1)
         if (d->transposed && d->c_out == 16 && d->k == 4 && d->stride == 2 && d->padding == 1 && d->act == ACT_NONE) c->valu_kind = 2;
         if (c->valu_kind) {
             const size_t n = (size_t)d->c_in * d->c_out * d->k;
@@ -365,7 +367,8 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         ProfRec rec{};
         const double macs = (double)B * c->d.c_out * c->d.c_in * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 6 + c->valu_kind, 2.0 * macs, 4.0 * B * ((double)c->d.c_in * Tin + (double)c->d.c_out * Tout), s));
-        if (c->valu_kind == 1) hipLaunchKernelGGL(conv1_valu_kernel<7>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
+        if (c->valu_kind == 1 && c->d.k == 7) hipLaunchKernelGGL(conv1_valu_kernel<7>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
+        else if (c->valu_kind == 1) hipLaunchKernelGGL(conv1_valu_kernel<1>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
         else hipLaunchKernelGGL((convt_valu_kernel<16, 4, 2, 1>), dim3((Tin + 255) / 256, B), dim3(256), 0, s, q);
         HIP_TRY(hipGetLastError());
         if (g_prof_on) TRY(prof_close(rec, s));

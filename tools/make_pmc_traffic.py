@@ -19,7 +19,7 @@ def norm(name: str) -> str:
     m = re.match(r"(conv_bf16x6_kernel<\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
     if m:
         return m.group(1) + ">"
-    return re.sub(r"^(resblock_bf16x6_kernel)<\d+>$", r"\1", name)  # 32- and 64-channel instantiations share bench.py's row
+    return re.sub(r"^(resblock_bf16x6_kernel|conv1_valu_kernel)<\d+>$", r"\1", name)  # instantiations that share one bench.py row
 
 
 def load(path: str, col: str):
