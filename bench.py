@@ -205,7 +205,9 @@ def main():
         split = "bf16x6" in dom["kernel"]
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                "peak_note": ("dense bf16 MFMA peak 2500 TF / 6 MFMAs per algorithmic fp32 FMA" if split else "fp32 MFMA peak"),
+                "peak_note": ("dense bf16 MFMA peak 2500 TF / 6 MFMAs per algorithmic fp32 FMA; the kernel is clock/power-limited on real "
+                              "data: the same instruction stream on constant operands runs 1.36x faster (DESIGN.md section 7, "
+                              "tools/microbench_conv.py --constant)" if split else "fp32 MFMA peak"),
                 "frac": dom["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": dom["avg_us"],
                 "launches_per_step": dom["launches_per_step"], "alg_GBps": dom["alg_gbs"], "all_conv_kernels": rows}
         res = {
