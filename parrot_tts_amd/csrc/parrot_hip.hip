@@ -823,7 +823,8 @@ extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, co
             const float* r = X;
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
-            if (fused_mode() != 0 && v->rb_stream[(size_t)i * nk + j]) {
+            // (the fused kernels address a batch row with 32-bit byte offsets: rows of 2 GiB and more go layer by layer)
+            if (fused_mode() != 0 && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
                 TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, s, unit_lens, mul));
                 continue;
             }
