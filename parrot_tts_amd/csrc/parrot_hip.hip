@@ -357,7 +357,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     if (B <= 0 || Tin <= 0) return fail(PARROT_E_INVALID, "conv_run: empty batch or sequence");
     const int Tout = c->out_len(Tin);
     if (Tout <= 0) return fail(PARROT_E_INVALID, "conv_run: sequence shorter than the kernel");
-    if (c->valu_kind && !res && epi == EPI_STORE && x_bstride <= 0 && y_bstride <= 0) {
+    if (c->valu_kind && !res && epi == EPI_STORE && x_bstride <= 0 && y_bstride <= 0 && (double)c->d.c_in * Tin * 4.0 < 2147483648.0) {
         ConvValuParams q{};
         q.x = x; q.w = c->wraw; q.bias = c->bias; q.y = y;
         q.B = B; q.Cin = c->d.c_in; q.Tin = Tin; q.Tout = Tout;
