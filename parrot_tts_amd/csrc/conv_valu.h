@@ -65,6 +65,55 @@ __global__ __launch_bounds__(256) void conv1_valu_kernel(const ConvValuParams p)
     }
 }
 
+// The same for K = 7 with 16-byte loads (rows that are a multiple of 4 samples long): the ten inputs of a thread's four
+// outputs are the three aligned quads at t0 - 4, t0, t0 + 4 -- 3 buffer_load_dwordx4 per channel instead of 10 strided
+// dword loads (the texture-address path, not HBM, bounded the dword version at 1.9 TB/s).  A quad is either inside
+// the row or entirely outside it (-> 0); only a ragged row end (Tlim % 4 != 0) needs per-sample masking.
+__global__ __launch_bounds__(256) void conv1_valu7_vec_kernel(const ConvValuParams p) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.y;
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;
+    const __amdgpu_buffer_rsrc_t xr = valu_row_rsrc(p.x + (size_t)b * p.Cin * p.Tin);
+    int voff[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int t = t0 + 4 * (q - 1);
+        voff[q] = (t >= 0 && t < Tlim) ? t * 4 : (int)0x80000000;
+    }
+    const bool partial = (Tlim & 3) != 0;  // the quad that straddles the row end carries samples of the padding region
+    const float b0 = p.bias ? p.bias[0] : 0.f;
+    float acc[4] = {b0, b0, b0, b0};
+    const int row_bytes = p.Tin * 4;
+    for (int c = 0; c < p.Cin; ++c) {
+        float v[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const f32x4v xv = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[q], c * row_bytes, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float xe = xv[e];
+                if (partial) xe = (t0 + 4 * (q - 1) + e < Tlim) ? xe : 0.f;
+                v[4 * q + e] = fmaxf(xe, xe * p.slope);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const float wj = p.w[c * 7 + j];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] = fmaf(wj, v[o + j + 1], acc[o]);  // input t0 + o + j - 3 = v[(o + j - 3) + 4]
+        }
+    }
+    f32x4v r;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) r[o] = (p.act == ACT_TANH) ? tanhf(acc[o]) : acc[o];
+    if (t0 + 3 < p.Tout) *reinterpret_cast<f32x4v*>(p.y + (size_t)b * p.Tout + t0) = r;
+    else
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (t0 + o < p.Tout) p.y[(size_t)b * p.Tout + t0 + o] = r[o];
+}
+
 // ConvTranspose1d, COUT output channels, kernel K, stride U, padding PAD, in polyphase form: a lane owns input position
 // n and produces outputs t = n*U + ph, ph < U, for every output channel:
 //     y[o][n*U + ph] = b[o] + sum_c sum_{kap : (ph + PAD - kap) % U == 0} w[c][o][kap] * pre(x[c][n + (ph + PAD - kap) / U])

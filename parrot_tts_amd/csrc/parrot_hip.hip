@@ -367,7 +367,9 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         ProfRec rec{};
         const double macs = (double)B * c->d.c_out * c->d.c_in * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 6 + c->valu_kind, 2.0 * macs, 4.0 * B * ((double)c->d.c_in * Tin + (double)c->d.c_out * Tout), s));
-        if (c->valu_kind == 1 && c->d.k == 7) hipLaunchKernelGGL(conv1_valu_kernel<7>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
+        if (c->valu_kind == 1 && c->d.k == 7 && (Tin & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0)
+            hipLaunchKernelGGL(conv1_valu7_vec_kernel, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
+        else if (c->valu_kind == 1 && c->d.k == 7) hipLaunchKernelGGL(conv1_valu_kernel<7>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
         else if (c->valu_kind == 1) hipLaunchKernelGGL(conv1_valu_kernel<1>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
         else hipLaunchKernelGGL((convt_valu_kernel<16, 4, 2, 1>), dim3((Tin + 255) / 256, B), dim3(256), 0, s, q);
         HIP_TRY(hipGetLastError());
