@@ -154,13 +154,19 @@ __global__ __launch_bounds__(256) void convt_valu_kernel(const ConvValuParams p)
     }
     if (n < p.Tin) {
         float* yb = p.y + (size_t)b * COUT * p.Tout;
+        if (U == 2 && (p.Tout & 1) == 0 && n * 2 + 1 < p.Tout) {  // the two phases of a lane are adjacent samples: 8-byte stores
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int o = 0; o < COUT; ++o)
+            for (int o = 0; o < COUT; ++o) *reinterpret_cast<f32x2v*>(yb + (size_t)o * p.Tout + 2 * n) = f32x2v{acc[o][0], acc[o][U - 1]};
+        } else {
 #pragma unroll
-            for (int ph = 0; ph < U; ++ph) {
-                const int t = n * U + ph - 0;
-                if (t < p.Tout) yb[(size_t)o * p.Tout + t] = acc[o][ph];
-            }
+            for (int o = 0; o < COUT; ++o)
+#pragma unroll
+                for (int ph = 0; ph < U; ++ph) {
+                    const int t = n * U + ph;
+                    if (t < p.Tout) yb[(size_t)o * p.Tout + t] = acc[o][ph];
+                }
+        }
     }
 }
 
