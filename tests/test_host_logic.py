@@ -161,3 +161,23 @@ def test_shard_rows_partition():
             assert flat == list(range(n))
             sizes = [s.stop - s.start for s in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_profile_kernel_names_fold_to_bench_rows():
+    """tools/make_pmc_traffic.norm maps rocprofv3's instantiation names onto the rows bench.py reports (TILE_NAMES), so
+    `roofline.traffic` finds the dominant kernel's PMC entry."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_pmc_traffic", os.path.join(root, "tools", "make_pmc_traffic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import bench
+    cases = {"conv_bf16x6_kernel<2, 2, 2, 2, 2, 11, 1>": "conv_bf16x6_kernel<2,2,2,2,2>",
+             "conv_bf16x6_kernel<2, 2, 2, 1, 3, 1, 4>": "conv_bf16x6_kernel<2,2,2,1,3>",
+             "conv_bf16x6_kernel<1, 4, 1, 4, 2, 3, 1>": "conv_bf16x6_kernel<1,4,1,4,2>",
+             "resblock_bf16x6_kernel<4>": "resblock_bf16x6_kernel", "resblock16_bf16x6_kernel": "resblock16_bf16x6_kernel",
+             "conv1_valu_kernel<7>": "conv1_valu_kernel", "conv1_valu7_vec_kernel": "conv1_valu_kernel", "convt_valu_kernel<16, 4, 2, 1>": "convt_valu_kernel<16,4,2,1>",
+             "conv_mfma_kernel<2, 2, 2, 2, 16, 3>": "conv_mfma_kernel<2,2,2,2,16,3>"}
+    for raw, want in cases.items():
+        assert mod.norm(raw) == want
+        assert want in bench.TILE_NAMES

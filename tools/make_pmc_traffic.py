@@ -19,6 +19,8 @@ def norm(name: str) -> str:
     m = re.match(r"(conv_bf16x6_kernel<\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
     if m:
         return m.group(1) + ">"
+    if name == "conv1_valu7_vec_kernel":
+        return "conv1_valu_kernel"
     return re.sub(r"^(resblock_bf16x6_kernel|conv1_valu_kernel)<\d+>$", r"\1", name)  # instantiations that share one bench.py row
 
 
