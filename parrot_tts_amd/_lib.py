@@ -103,6 +103,10 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -m parrot_tts_amd.build` (hipcc, gfx950). "
                               "parrot_tts_amd has no CPU fallback.")
+        # torch first, always: it brings its own HIP runtime, and the library must bind to THAT copy -- loaded the other
+        # way round (e.g. __graft_entry__.build() before the first `import torch`) the process ends up with two
+        # runtimes and the second one sees no device
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
