@@ -158,7 +158,7 @@ static int g_default_prec = -1;
 static int default_prec() {
     if (g_default_prec < 0) {
         const char* e = getenv("PARROT_PRECISION");
-        g_default_prec = (e && (!strcmp(e, "bf16x6") || !strcmp(e, "1"))) ? 1 : 0;
+        g_default_prec = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;  // split-bf16 unless the exact mode is asked for
     }
     return g_default_prec;
 }

@@ -68,7 +68,7 @@ def prec(request):
     Both are held to the SAME tolerances."""
     ops.set_default_precision(ops.PREC_BF16X6 if request.param == "bf16x6" else ops.PREC_F32)
     yield request.param
-    ops.set_default_precision(ops.PREC_F32)
+    ops.set_default_precision(ops.PREC_BF16X6)  # the library default
 
 
 # ----------------------------------------------------------------------------------------------
