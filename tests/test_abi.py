@@ -48,3 +48,45 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.TteCfg) == 14 * 4
     n_int = 7 + 8 + 8 + 1 + 4 + 1 + 16 + 1
     assert ctypes.sizeof(_lib.VocCfg) == n_int * 4
+
+
+def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
+    """The boundary is a C ABI: include/parrot_hip.h compiles as C (gcc -std=c99 -pedantic) and a C program binds the
+    entry points by name with dlopen -- no C++ or torch types involved."""
+    import shutil
+    import subprocess
+    from parrot_tts_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('''
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+#include "parrot_hip.h"
+int main(int argc, char** argv) {
+    void* h = dlopen(argv[1], RTLD_NOW);
+    if (!h) { fprintf(stderr, "%s\\n", dlerror()); return 2; }
+    int (*ver)(void) = (int (*)(void))dlsym(h, "parrot_abi_version");
+    const char* (*err)(void) = (const char* (*)(void))dlsym(h, "parrot_last_error");
+    int (*run)(parrot_conv_t*, const float*, const float*, float*, int32_t, int32_t, int32_t, float, void*) =
+        (int (*)(parrot_conv_t*, const float*, const float*, float*, int32_t, int32_t, int32_t, float, void*))dlsym(h, "parrot_conv_run");
+    if (!ver || !err || !run) return 3;
+    if (ver() != 1) return 4;
+    if (run(NULL, NULL, NULL, NULL, 1, 1, 0, 1.0f, NULL) != PARROT_E_INVALID) return 5;
+    if (!strstr(err(), "null")) return 6;
+    printf("ok\\n");
+    return 0;
+}
+''')
+    hdr = tmp_path / "hdr.c"
+    hdr.write_text('#include "parrot_hip.h"\nint parrot_header_only_tu;\n')
+    subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(hdr)], check=True)
+    exe = tmp_path / "abi"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-ldl"], check=True)
+    env = dict(os.environ)
+    import torch
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([str(exe), _lib.LIB_PATH], check=True, capture_output=True, text=True, env=env)
+    assert out.stdout.strip() == "ok"
