@@ -36,12 +36,18 @@ from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 HBM_PEAK_GBS = 8000.0
 SAMPLE_RATE = 16000             # reference utils/vocoder/config.json:32 (the metric's "22.05 kHz" does not match the reference)
+# rows of parrot_prof_end, in the library's order; SCH = the split scheme of the run (conv_split.h)
 TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>", "conv_mfma_kernel<1,4,1,4,16,2>",
               "conv_mfma_kernel<2,2,2,2,32,3>", "conv_mfma_kernel<2,2,2,1,16,3>", "conv_mfma_kernel<1,4,1,2,16,4>",
-              "conv_mfma16_kernel<8,2>", "conv_bf16x6_kernel<2,2,2,2,2>", "conv_bf16x6_kernel<1,4,2,2,2>", "resblock_fused16_kernel",
-              "conv_bf16x6_kernel<2,2,2,1,3>", "conv_bf16x6_kernel<1,4,1,4,2>", "resblock_bf16x6_kernel", "resblock16_bf16x6_kernel",
+              "conv_mfma16_kernel<8,2>", "conv_split_kernel<SCH,2,2,2,2,2>", "conv_split_kernel<SCH,1,4,2,2,2>", "resblock_fused16_kernel",
+              "conv_split_kernel<SCH,2,2,2,1,3>", "conv_split_kernel<SCH,1,4,1,4,2>", "resblock_split_kernel<SCH>", "resblock16_split_kernel<SCH>",
               "conv1_valu_kernel", "convt_valu_kernel<16,4,2,1>"]
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the split scheme spends 6 bf16 MFMA FMAs per algorithmic fp32 FMA
+SCHEMES = {"f16x3": ("SchF16x3", 3), "bf16x6": ("SchBf16x6", 6), "bf16": ("SchBf16", 1), "f16": ("SchF16", 1), "f32": ("-", 1)}
+MFMA16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split scheme spends 3 (f16x3) or 6 (bf16x6) MFMA FMAs per algorithmic fp32 FMA
+
+
+def tile_names(precision):
+    return [n.replace("SCH", SCHEMES[precision][0]) for n in TILE_NAMES]
 
 
 def pmc_traffic(kernel: str):
@@ -76,12 +82,29 @@ def build_models(dev, vocab=300, n_spk=10):
     return cfg, h, tsd, vsd, parrot.eval().to(dev), gen.to(dev)
 
 
+def physical_cores():
+    """Physical cores of this host (unique (package, core) pairs), falling back to the logical count."""
+    try:
+        seen, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip() and phys is not None and core is not None:
+                seen.add((phys, core))
+                phys = core = None
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(cfg, h, tsd, vsd, B, S, vocab, n_spk):
     """The oracle (CPU restatement, parity-pinned to the reference) timed on this host's cores on a bounded
     sample of the same workload: B utterances of the full pipeline."""
     from oracle import parrot_oracle as O
     # more threads than ~64 only adds oversubscription on these layer sizes (256 threads: 100 s / pass)
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(physical_cores(), 64)
     torch.set_num_threads(cores)
     batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=0)
     folded = O.fold_weight_norm(vsd)
@@ -100,7 +123,8 @@ def cpu_baseline(cfg, h, tsd, vsd, B, S, vocab, n_spk):
         ts.append(time.perf_counter() - t0)
     best = min(ts)
     n = y.shape[0] * y.shape[-1]
-    return {"value": n / best, "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": n / best, "unit": "samples/s", "cores": cores, "host_physical_cores": physical_cores(), "host_logical_cpus": os.cpu_count(),
+            "kind": "port",
             "sample": f"oracle full pipeline (TTE S={S}->L={y.shape[-1] // 320} + HiFi-GAN), batch {B}, fp32, torch-CPU {cores} threads, "
                       f"best of 2 after 1 warm-up ({best:.2f} s/pass)",
             "rtf": best / (n / SAMPLE_RATE)}
@@ -120,14 +144,15 @@ def main():
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("PARROT_BENCH_OVERLAP", "0")),
                     help="1: the headline run itself uses the two-stage pipeline across steps (TTE of batch i on a side stream beside "
                          "the vocoder of batch i-1); default 0: one batch at a time, the pipelined rate is reported next to it")
-    ap.add_argument("--precision", choices=["f32", "bf16x6"], default=os.environ.get("PARROT_BENCH_PRECISION", "bf16x6"),
-                    help="product evaluation of the conv kernels for layers with >= 16 channels (fp32 data either way)")
+    ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "bf16", "f16"], default=os.environ.get("PARROT_BENCH_PRECISION", "f16x3"),
+                    help="product evaluation of the conv kernels for layers with >= 16 channels (fp32 data either way): f16x3 (default), "
+                         "bf16x6 and f32 are parity-grade; bf16 / f16 are the single-MFMA reduced-precision operating point")
     a = ap.parse_args()
 
     rank, world, local = pdist.init_from_env("nccl")
     if world != a.gpus:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    dev = torch.device("cuda", local)
+    dev = pdist.local_device(local)
     torch.cuda.set_device(dev)
     vocab, n_spk = 300, 10
     from parrot_tts_amd import ops
@@ -143,7 +168,7 @@ def main():
         """Build both models under `precision`, then W untimed + K timed steps.  Returns (max-over-ranks seconds,
         per-kernel profile rows, samples per step over all ranks, model pieces for the CPU baseline)."""
         workload = workload or a.workload
-        ops.set_default_precision(ops.PREC_BF16X6 if precision == "bf16x6" else ops.PREC_F32)
+        ops.set_default_precision(ops.PREC_NAMES[precision])
         cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
         pipe = SynthesisPipeline(parrot, gen)
         batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(B, S, vocab, n_spk, seed=rank).items()}
@@ -154,13 +179,13 @@ def main():
         def finish(out):
             if out is None:
                 return None
-            return pdist.gather_waveforms(out["wav"], dst=0) if world > 1 else out["wav"]
+            return pdist.gather_waveforms(out["wav"], dst=0, equal_shapes=True) if world > 1 else out["wav"]
 
         def step():
             if overlap:  # TTE of this batch beside the vocoder of the previous one; results one call late
                 return finish(pipe.submit(batch))
             wav = pipe(batch)["wav"] if workload == "full" else gen(code=vb["code"], spkr=vb["spkr"])
-            return pdist.gather_waveforms(wav, dst=0) if world > 1 else wav
+            return pdist.gather_waveforms(wav, dst=0, equal_shapes=True) if world > 1 else wav  # forced durations: every shard is (B, 1, 320 L)
 
         def drain():  # every submitted batch is finished inside the region that submitted it
             return finish(pipe.flush()) if overlap else None
@@ -179,13 +204,14 @@ def main():
         wav = out if out is not None else wav
         fence()
         elapsed = time.perf_counter() - t0
-        prof = (C.c_double * (4 * len(TILE_NAMES)))()
-        _lib.check(lib.parrot_prof_end(prof, len(TILE_NAMES)))
+        names = tile_names(precision)
+        prof = (C.c_double * (4 * len(names)))()
+        _lib.check(lib.parrot_prof_end(prof, len(names)))
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         rows = []
-        for i, nm in enumerate(TILE_NAMES):
+        for i, nm in enumerate(names):
             n, tms, fl, by = prof[4 * i: 4 * i + 4]
             if n > 0:
                 rows.append({"kernel": nm, "launches_per_step": n / steps, "avg_us": tms / n * 1e3, "ms_per_step": tms / steps,
@@ -195,6 +221,25 @@ def main():
         del pipe, parrot, gen
         return float(t.item()), rows, n_samples, (cfg, h, tsd, vsd)
 
+    def long_form(precision, steps, B=8, U=1500, chunk=256):
+        ops.set_default_precision(ops.PREC_NAMES[precision])
+        cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
+        vb = {k: v.to(dev) for k, v in synth.synth_voc_batch(B, U, h, seed=3).items()}
+        out = {}
+        for name, fn in (("whole", lambda: gen(code=vb["code"], spkr=vb["spkr"])),
+                         ("chunk_streamed_256", lambda: gen.forward_chunked(chunk_units=chunk, code=vb["code"], spkr=vb["spkr"]))):
+            fn()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                w = fn()
+            fence()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            out[name] = {"value": B * w.shape[-1] / (ms / 1e3), "unit": "samples/s", "ms_per_step": ms}
+        out["workload"] = "HiFi-GAN generator, batch %d x %d units (30 s utterances), whole and in %d-unit chunks with a 20-unit halo (BASELINE configs[4])" % (B, U, chunk)
+        del parrot, gen
+        return out
+
     elapsed, rows, n_samples_step, pieces = run(a.precision, a.steps, a.warmup, overlap_steps=bool(a.overlap))
 
     if rank == 0:
@@ -202,21 +247,26 @@ def main():
         value = n_samples_step / (ms / 1e3)
         dom = rows[0]
         traffic, traffic_src = pmc_traffic(dom["kernel"])
-        split = "bf16x6" in dom["kernel"]
-        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+        split = "_split_kernel" in dom["kernel"]
+        n_mfma = SCHEMES[a.precision][1]
+        peak = MFMA16_PEAK_TFLOPS / n_mfma if split else FP32_MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                "peak_note": ("dense bf16 MFMA peak 2500 TF / 6 MFMAs per algorithmic fp32 FMA; the kernel is clock/power-limited on real "
-                              "data: the same instruction stream on constant operands runs 1.36x faster (DESIGN.md section 7, "
-                              "tools/microbench_conv.py --constant)" if split else "fp32 MFMA peak"),
+                "peak_note": (f"dense 16-bit MFMA peak 2500 TF / {n_mfma} MFMA(s) per algorithmic fp32 FMA ({a.precision}); the kernels are "
+                              "clock/power-limited on real data (DESIGN.md section 7)" if split else "fp32 MFMA peak"),
                 "frac": dom["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": dom["avg_us"],
                 "launches_per_step": dom["launches_per_step"], "alg_GBps": dom["alg_gbs"], "all_conv_kernels": rows}
         res = {
             "metric": "audio samples/sec (16 kHz; see config.note) + RTF, 256-unit batch-64 per GPU",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "precision": ("fp32 data/accumulate; products of layers with >=16 channels evaluated as 6 bf16 MFMAs on 3-way "
-                          "bf16 splits of both fp32 operands (fp32-class error, same parity tolerances); other layers exact fp32 MFMA")
-            if a.precision == "bf16x6" else "exact fp32 MFMA everywhere",
+            "precision": {"f16x3": "fp32 data/accumulate; products of layers with >=16 channels evaluated as 3 fp16 MFMAs on 2-way fp16 splits "
+                                   "of both (power-of-two pre-scaled) fp32 operands: fp32-class error, same parity tolerances; other layers exact fp32 MFMA",
+                          "bf16x6": "fp32 data/accumulate; products of layers with >=16 channels evaluated as 6 bf16 MFMAs on 3-way bf16 splits of "
+                                    "both fp32 operands (fp32-class error, same parity tolerances); other layers exact fp32 MFMA",
+                          "f32": "exact fp32 MFMA everywhere",
+                          "bf16": "REDUCED precision: operands rounded once to bf16, one MFMA per product group, fp32 accumulate / residual stream",
+                          "f16": "REDUCED precision: operands rounded once to fp16, one MFMA per product group, fp32 accumulate / residual stream",
+                          }[a.precision],
             "rtf": (ms / 1e3) / (n_samples_step / SAMPLE_RATE),
             "config": {"workload": ("full TTE(S=%d)->length-regulator(L=%d)->HiFi-GAN(%d samples/utt)" % (S, 4 * S, 4 * S * 320))
                        if a.workload == "full" else "HiFi-GAN generator only, %d units" % (4 * S),
@@ -240,22 +290,45 @@ def main():
             "schedule": "one batch at a time" if a.overlap else "TTE of batch i on a side HIP stream beside the vocoder of batch i-1 "
                         "(SynthesisPipeline.submit / flush); all submitted batches finish inside the timed region"}
     if world == 1 and a.workload == "full" and not a.no_alt:
-        # BASELINE.json configs[1]: HiFi-GAN generator only, batch 32 x 256 units
-        e3, _, n3, _ = run(a.precision, a.steps, max(a.warmup, 3), workload="vocoder", B=32)
-        ms3 = e3 / a.steps * 1e3
-        res["vocoder_only_b32"] = {"value": n3 / (ms3 / 1e3), "unit": "samples/s", "ms_per_step": ms3, "steps": a.steps,
-                                   "workload": "HiFi-GAN generator only, batch 32 x %d units (BASELINE configs[1])" % (4 * S)}
-    if world == 1 and a.precision == "bf16x6" and not a.no_alt:
+        # BASELINE.json configs[1]: HiFi-GAN generator only, batch 32 x 256 units -- in the run's precision and, as the
+        # config is worded ("fp32"), with every product on the exact fp32 MFMA
+        for key, prec_ in (("vocoder_only_b32", a.precision), ("vocoder_only_b32_exact_fp32", "f32")):
+            e3, rows3, n3, _ = run(prec_, a.steps if prec_ != "f32" else min(a.steps, 5), max(a.warmup, 2), workload="vocoder", B=32)
+            ms3 = e3 / (a.steps if prec_ != "f32" else min(a.steps, 5)) * 1e3
+            res[key] = {"value": n3 / (ms3 / 1e3), "unit": "samples/s", "ms_per_step": ms3, "precision": prec_,
+                        "workload": "HiFi-GAN generator only, batch 32 x %d units (BASELINE configs[1])" % (4 * S),
+                        "dominant_kernel": rows3[0]["kernel"], "dominant_tflops": rows3[0]["tflops"]}
+        # BASELINE.json configs[0] shape: ONE utterance end to end (latency-bound: ~130 launches)
+        e4, _, n4, _ = run(a.precision, a.steps, max(a.warmup, 3), B=1)
+        ms4 = e4 / a.steps * 1e3
+        res["single_utterance_b1"] = {"value": n4 / (ms4 / 1e3), "unit": "samples/s", "ms_per_step": ms4, "rtf": (ms4 / 1e3) / (n4 / SAMPLE_RATE),
+                                      "workload": "full pipeline, ONE utterance (S=%d -> %d units), BASELINE configs[0] shape" % (S, 4 * S)}
+        # BASELINE.json configs[4]: long-form 30 s utterances, batch 8 x 1500 units, chunk-streamed vocoder (256-unit chunks)
+        res["long_form_b8_u1500"] = long_form(a.precision, min(a.steps, 5))
+    if world == 1 and a.precision != "f32" and not a.no_alt:
         # the same workload with every product on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32), for reference
         e2, rows2, n2, _ = run("f32", min(a.steps, 5), 1)
         ms2 = e2 / min(a.steps, 5) * 1e3
         res["exact_fp32_mfma"] = {"value": n2 / (ms2 / 1e3), "unit": "samples/s", "ms_per_step": ms2, "steps": min(a.steps, 5),
                                   "dominant_kernel": rows2[0]["kernel"], "dominant_tflops": rows2[0]["tflops"],
                                   "frac_of_fp32_mfma_peak": rows2[0]["tflops"] / FP32_MFMA_PEAK_TFLOPS}
+    if world == 1 and a.precision in ("f16x3", "bf16x6", "f32") and not a.no_alt:
+        # BASELINE.json configs[2] names a bf16 vocoder: the reduced-precision operating point as a COMPANION line (never the
+        # headline): fp32 TTE kernels' products and the vocoder's on ONE bf16 MFMA, fp32 accumulate / residual stream.
+        # SNR vs the fp32 reference waveform: tests/test_gpu_baseline_shapes.py (>= 35.9 dB, the reference under autocast).
+        for key, prec_ in (("bf16_vocoder", "bf16"), ("f16_vocoder", "f16")):
+            e5, rows5, n5, _ = run(prec_, a.steps, max(a.warmup, 2))
+            ms5 = e5 / a.steps * 1e3
+            res[key] = {"value": n5 / (ms5 / 1e3), "unit": "samples/s", "ms_per_step": ms5, "precision": prec_,
+                        "note": "reduced precision (single %s MFMA per product group, fp32 accumulate): NOT parity-grade, companion to the headline" % prec_[:4],
+                        "dominant_kernel": rows5[0]["kernel"], "dominant_tflops": rows5[0]["tflops"]}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             cfg, h, tsd, vsd = pieces
             res["cpu_baseline"] = cpu_baseline(cfg, h, tsd, vsd, a.cpu_batch, S, vocab, n_spk)
+            # the demo-style single utterance (BASELINE configs[0]); B=64 on the CPU would take ~45 s per pass and is
+            # not run: B=8 above is already at the CPU's throughput plateau
+            res["cpu_baseline_b1"] = cpu_baseline(cfg, h, tsd, vsd, 1, S, vocab, n_spk)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PARROT_ABI_VERSION 1
+#define PARROT_ABI_VERSION 2
 
 enum {
     PARROT_OK = 0,
@@ -64,18 +64,29 @@ typedef struct {
     int32_t precision;                         /* PARROT_PREC_*; -1 = library default            */
 } parrot_conv_desc;
 
-/* How fp32 products are evaluated.  Inputs, outputs, residuals and accumulation are fp32 in both modes.
+/* How the fp32 products of layers with >= 16 channels are evaluated.  Inputs, outputs, residual stream and accumulation
+ * are fp32 in every mode (csrc/conv_split.h has the details).
  *   PARROT_PREC_F32    v_mfma_f32_32x32x2_f32: exact fp32 fma chain.
- *   PARROT_PREC_BF16X6 each operand split into 3 bf16 pieces, 6 bf16 MFMAs per product group (terms below
- *                      2^-23 of the product dropped), fp32 accumulate: fp32-class error at 16/6 the MFMA rate;
- *                      used for layers with >= 16 channels (incl. the fused ResBlock kernels), the rest stays exact.
- *                      Parity-tested to the same tolerances as PARROT_PREC_F32 and 1.9x faster end to end.
- * Default: PARROT_PRECISION env ("f32" | "bf16x6") at first use, else bf16x6; or set it here before *_create. */
+ *   PARROT_PREC_F16X3  (default) each operand split into 2 fp16 pieces (pre-scaled by powers of two), 3 fp16 MFMAs per
+ *                      product group (dropped term <= 2^-22 of the product), fp32 accumulate: fp32-class error, held to
+ *                      the same parity tolerances as PARROT_PREC_F32, at 16/3 the MFMA rate.  Activations must stay
+ *                      below 8190 in magnitude (fp16 range after the 2^3 pre-scale): beyond that the output turns
+ *                      into inf/NaN, never into a silently wrong finite value.
+ *   PARROT_PREC_BF16X6 each operand split into 3 bf16 pieces, 6 bf16 MFMAs per product group (dropped terms <= 2^-23),
+ *                      fp32's full exponent range; same tolerances, 16/6 the MFMA rate.
+ *   PARROT_PREC_BF16 / PARROT_PREC_F16   operands rounded once to bf16 / fp16, ONE MFMA per product group, fp32
+ *                      accumulate, fp32 residual stream: the reduced-precision operating point (BASELINE configs[2]
+ *                      "bf16"); NOT parity-grade -- reported by SNR against the fp32 result (36 dB / 54 dB).
+ * The process-wide default (PARROT_PRECISION env: "f32" | "f16x3" | "bf16x6" | "bf16" | "f16", else f16x3; or the setter)
+ * is read ONCE by every *_create: a handle keeps the mode it was created under and is immutable afterwards. */
 #define PARROT_PREC_F32 0
 #define PARROT_PREC_BF16X6 1
+#define PARROT_PREC_F16X3 2
+#define PARROT_PREC_BF16 3
+#define PARROT_PREC_F16 4
 int parrot_set_default_precision(int32_t prec);
-/* Whole-ResBlock fused kernels (csrc/resblock_fused.h): 0 off, 1 stages with 16 and 32 channels, 2 only 16-channel
- * stages (default; env PARROT_FUSED overrides).  Takes effect at the next forward. */
+/* Fused ResBlock kernels (csrc/resblock_split.h, resblock_fused.h): 0 off (layer by layer), 1 every eligible stage,
+ * 2 (default; env PARROT_FUSED) all but the exact-fp32 32-channel kernel.  Default for handles created afterwards. */
 int parrot_set_fused_resblocks(int32_t mode);
 
 int parrot_conv_create(parrot_conv_t** out, const parrot_conv_desc* d, const float* w_host, const float* bias_host);
@@ -208,6 +219,19 @@ int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L,
 /* Device-side id-range flag (a bad phone / unit / speaker id <-> the reference's Embedding
  * IndexError).  Synchronises `stream`; returns 0 or PARROT_E_RANGE and clears the flag.       */
 int parrot_tte_check(parrot_tte_t*, void* stream);
+/* Tests / error localisation: while set, the next encode / decode calls copy the channel-first (B, D, T) activation
+ * after each stage to the given DEVICE buffers (NULL entries are skipped): enc_ptrs[0] = embedding + pe[S],
+ * enc_ptrs[1 + n] = encoder block n, enc_ptrs[1 + enc_layers] = encoder output (+ speaker); dec_ptrs[0] = length
+ * regulator output + pe[L], dec_ptrs[1 + n] = decoder block n.  Pass NULL, NULL to switch it off. */
+int parrot_tte_debug_stages(parrot_tte_t*, float* const* enc_ptrs, float* const* dec_ptrs);
+
+/* length_regulator alone (modules/duration.py:6-24 + modules/data.py:8-20), on the kernel the decoder uses:
+ * seq (B,S,D) f32 as the reference holds it, dur (B,S) i64 -> out (B,L,D) (rows repeat_interleave'd, zero right-padded),
+ * mask (B,L) u8 = ids <= len (quirk Q2), out_lens (B) i32.  L = max over rows of sum(dur), computed by the caller like
+ * duration.py:10; ws: 2*B*D*max(S,L) floats + B*S + B int32 (parrot_length_regulator_workspace_bytes). */
+size_t parrot_length_regulator_workspace_bytes(int32_t B, int32_t S, int32_t D, int32_t L);
+int parrot_length_regulator(const float* seq, const int64_t* dur, int32_t B, int32_t S, int32_t D, int32_t L, float* out,
+                            uint8_t* mask, int32_t* out_lens, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

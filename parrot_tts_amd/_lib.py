@@ -91,6 +91,9 @@ SIGNATURES = {
     "parrot_tte_encode": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_decode": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_check": (C.c_int, [vp, vp]),
+    "parrot_tte_debug_stages": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+    "parrot_length_regulator_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "parrot_length_regulator": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
 }
 
 _lib = None
@@ -111,7 +114,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.parrot_abi_version() != 1:
+        if handle.parrot_abi_version() != 2:
             raise ImportError("libparrot_hip.so ABI version mismatch")
         _lib = handle
     return _lib

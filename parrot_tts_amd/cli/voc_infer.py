@@ -37,7 +37,7 @@ def main(argv=None):
     ap.add_argument("--parts", action="store_true")
     a = ap.parse_args(argv)
     rank, world, local = pdist.init_from_env()
-    dev = torch.device("cuda", local)
+    dev = pdist.local_device(local)
     with open(a.config) as f:
         h = AttrDict(json.load(f))
     gen = load_generator(h, a.checkpoint_file, dev)

@@ -65,6 +65,8 @@ struct ConvParams {
     int u_inv16;         // ceil(65536 / u)
     const int32_t* row_len;  // optional per-batch-row true length (in base units); input positions >= row_len[b]*row_len_mul
     int row_len_mul;         // read as zero: each row then sees its OWN sequence edge (ragged batches); null = Tin for all
+    float acc_scale;         // split schemes with pre-scaled operands (conv_split.h): the accumulator holds acc_scale * sum
+    float out_scale;         // = 1 / acc_scale (both exact powers of two; 1 for every other kernel)
 };
 
 // ACT_TANH (conv_post only) is applied by tanh_inplace_kernel right after the conv launch: inlining tanhf
@@ -118,7 +120,14 @@ __device__ __forceinline__ void conv_acc_init(const ConvParams& p, f32x16 (&acc)
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bsv[r];
         }
     }
-
+    if (p.acc_scale != 1.f) {  // (uniform branch; a power of two: exact)
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= p.acc_scale;
+    }
 }
 
 template <int WM, int WN>
@@ -128,6 +137,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
     const bool plain = p.u == 1;
     const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
+    if (p.out_scale != 1.f) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= p.out_scale;
+    }
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     if ((p.u == 4 || p.u == 2) && p.Tout == p.Ncols * p.u) {
         // transposed conv with stride 4 / 2: the four consecutive rows a lane holds per register group (C/D layout) are

@@ -249,6 +249,33 @@ __global__ __launch_bounds__(256) void duration_kernel(const float* __restrict__
     }
 }
 
+// inclusive prefix sums + totals of given durations (parrot_length_regulator: the standalone entry point)
+__global__ __launch_bounds__(256) void dur_prefix_kernel(const int64_t* __restrict__ dur, int32_t* __restrict__ cum, int32_t* __restrict__ out_len, int S) {
+    __shared__ int32_t part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int per = (S + 255) / 256;
+    const int s_begin = min(S, tid * per), s_end = min(S, s_begin + per);
+    int32_t local = 0;
+    for (int s = s_begin; s < s_end; ++s) local += (int32_t)max(dur[(size_t)b * S + s], (int64_t)0);
+    part[tid] = local;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int32_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        out_len[b] = run;
+    }
+    __syncthreads();
+    int32_t run = part[tid];
+    for (int s = s_begin; s < s_end; ++s) {
+        run += (int32_t)max(dur[(size_t)b * S + s], (int64_t)0);
+        cum[(size_t)b * S + s] = run;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Length regulator + positional row (duration.py:6-24, parrot.py:106, data.py:8-20):
 // y[b, c, t] = (t < len_b ? enc[b, c, src(t)] : 0) + pe[L][c], src(t) = first s with cum[b,s] > t;

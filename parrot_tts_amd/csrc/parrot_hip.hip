@@ -5,20 +5,22 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "attn.h"
-#include "conv_bf16x6.h"
+#include "conv_split.h"
 #include "conv_mfma.h"
 #include "conv_mfma16.h"
 #include "conv_valu.h"
 #include "kernels_misc.h"
-#include "resblock_bf16x6.h"
+#include "resblock_split.h"
 #include "resblock_fused.h"
 
 using namespace parrot;
@@ -74,18 +76,26 @@ struct ProfRec {
     int cfg;
     double flops, bytes;
 };
-static bool g_prof_on = false;
+// (process-wide profiler: one mutex around its state; the flag is an atomic so un-profiled launches never take the lock)
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 
 static int prof_open(ProfRec& rec, int row, double flops, double bytes, hipStream_t s) {
-    if (g_prof_pool.empty()) {
+    bool fresh = false;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_pool.empty()) fresh = true;
+        else {
+            rec.a = g_prof_pool.back().first;
+            rec.b = g_prof_pool.back().second;
+            g_prof_pool.pop_back();
+        }
+    }
+    if (fresh) {
         HIP_TRY(hipEventCreate(&rec.a));
         HIP_TRY(hipEventCreate(&rec.b));
-    } else {
-        rec.a = g_prof_pool.back().first;
-        rec.b = g_prof_pool.back().second;
-        g_prof_pool.pop_back();
     }
     rec.cfg = row;
     rec.flops = flops;
@@ -95,11 +105,13 @@ static int prof_open(ProfRec& rec, int row, double flops, double bytes, hipStrea
 }
 static int prof_close(ProfRec& rec, hipStream_t s) {
     HIP_TRY(hipEventRecord(rec.b, s));
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(rec);
     return PARROT_OK;
 }
 
 extern "C" int parrot_prof_begin(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) g_prof_pool.push_back({r.a, r.b});
     g_prof.clear();
     g_prof_on = true;
@@ -109,6 +121,7 @@ extern "C" int parrot_prof_begin(void) {
 extern "C" int parrot_prof_end(double* out, int32_t n_cfg) {
     g_prof_on = false;
     if (!out || n_cfg <= 0) return fail(PARROT_E_INVALID, "prof_end: bad output buffer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < n_cfg * 4; ++i) out[i] = 0.0;
     for (auto& r : g_prof) {
         HIP_TRY(hipEventSynchronize(r.b));
@@ -136,9 +149,10 @@ struct parrot_conv {
     int nchunks = 0, n_it = 0;
     float* wfrag = nullptr;
     float* bias = nullptr;
-    int prec = 0;              // 0: exact fp32 MFMA, 1: split-bf16 (6 bf16 MFMAs per product group, fp32 accumulate)
-    uint16_t* wfrag16 = nullptr;
+    int prec = 0;              // 0: exact fp32 MFMA, else the split scheme of conv_split.h (PARROT_PREC_*: 16-bit MFMAs, fp32 accumulate)
+    uint16_t* wfrag16 = nullptr;  // [m_tile][chunk*tap][piece][lane][8 x 16 bit]
     int n_it16 = 0;
+    float wscale = 1.f;        // power-of-two weight scale inside the fp16 pieces (1 for bf16 schemes)
     int valu_kind = 0;         // 1: conv1_valu_kernel<7>, 2: convt_valu_kernel<16,4,2,1> (conv_valu.h); weights in their original layout
     float* wraw = nullptr;
 
@@ -154,20 +168,57 @@ struct parrot_conv {
     }
 };
 
-static int g_default_prec = -1;
+// Process-wide DEFAULTS, read once by every *_create (the handle keeps its own copy and is immutable afterwards, so
+// handles stay re-entrant; changing a default never affects a live handle).  Atomics: setters may race with creates.
+static std::atomic<int> g_default_prec{-1};
+static int parse_prec(const char* e) {
+    if (!e) return PARROT_PREC_F16X3;
+    if (!strcmp(e, "f32") || !strcmp(e, "0")) return PARROT_PREC_F32;
+    if (!strcmp(e, "bf16x6") || !strcmp(e, "1")) return PARROT_PREC_BF16X6;
+    if (!strcmp(e, "bf16") || !strcmp(e, "3")) return PARROT_PREC_BF16;
+    if (!strcmp(e, "f16") || !strcmp(e, "4")) return PARROT_PREC_F16;
+    return PARROT_PREC_F16X3;
+}
 static int default_prec() {
-    if (g_default_prec < 0) {
-        const char* e = getenv("PARROT_PRECISION");
-        g_default_prec = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;  // split-bf16 unless the exact mode is asked for
+    int v = g_default_prec.load();
+    if (v < 0) {
+        v = parse_prec(getenv("PARROT_PRECISION"));
+        g_default_prec.store(v);
     }
-    return g_default_prec;
+    return v;
 }
 extern "C" int parrot_set_default_precision(int32_t prec) {
-    if (prec != 0 && prec != 1) return fail(PARROT_E_INVALID, "set_default_precision: 0 (fp32 MFMA) or 1 (bf16x6)");
-    g_default_prec = prec;
+    if (prec < 0 || prec > PARROT_PREC_F16) return fail(PARROT_E_INVALID, "set_default_precision: PARROT_PREC_* (0..4)");
+    g_default_prec.store(prec);
     return PARROT_OK;
 }
 
+// Fused whole-ResBlock kernels: 0 off, 1 every eligible stage, 2 (default) all but the exact-fp32 32-channel kernel
+// (resblock_fused.h; slower than layer by layer).  PARROT_FUSED / parrot_set_fused_resblocks set the default for
+// handles created afterwards.
+static std::atomic<int> g_fused{-1};
+static int fused_mode() {
+    int v = g_fused.load();
+    if (v < 0) {
+        const char* e = getenv("PARROT_FUSED");
+        v = e ? atoi(e) : 2;
+        if (v < 0 || v > 2) v = 2;
+        g_fused.store(v);
+    }
+    return v;
+}
+
+static inline uint16_t f16_rn_host(float x) {  // round-to-nearest-even, overflow -> inf (what v_cvt_pk_f16_f32 does)
+    const _Float16 h = (_Float16)x;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+static inline float f16_to_f(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
 static inline uint16_t bf16_rn_host(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -179,6 +230,32 @@ static inline float bf16_to_f(uint16_t h) {
     float f;
     memcpy(&f, &u, 4);
     return f;
+}
+
+// Split-scheme weight pieces (conv_split.h).  fp16 schemes: the layer's weights are scaled by the power of two that puts
+// max|w| into [2^14, 2^15), so the second piece of every weight that matters is a normal fp16 number.
+static float f16_weight_scale(const float* w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
+    int e;
+    (void)std::frexp(mx, &e);  // mx = m * 2^e, m in [0.5, 1)
+    return std::ldexp(1.f, 15 - e);  // mx * scale in [2^14, 2^15)
+}
+static void split_weight(float v, int scheme, float wscale, uint16_t (&h)[3]) {
+    h[0] = h[1] = h[2] = 0;
+    if (scheme_is_f16(scheme)) {
+        const float vs = v * wscale;
+        h[0] = f16_rn_host(vs);
+        if (scheme == PARROT_PREC_F16X3) h[1] = f16_rn_host(vs - f16_to_f(h[0]));
+        return;
+    }
+    h[0] = bf16_rn_host(v);
+    if (scheme == PARROT_PREC_BF16X6) {
+        const float r1 = v - bf16_to_f(h[0]);
+        h[1] = bf16_rn_host(r1);
+        h[2] = bf16_rn_host(r1 - bf16_to_f(h[1]));
+    }
 }
 
 static int choose_cfg(int M, int k) {
@@ -292,35 +369,35 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
         return w[((size_t)m * Cing + i) * k + j];
     };
     const int want_prec = (d->precision >= 0) ? d->precision : default_prec();
-    // split kernel: at 32 rows it is slower than the exact one (measured); its slab fetch needs whole 16-channel chunks
+    if (want_prec > PARROT_PREC_F16) return fail(PARROT_E_INVALID, "conv_create: unknown precision");
+    // split kernels: at 32 rows the exact kernel is as fast (measured); the slab fetch needs whole 16-channel chunks
     // and evaluates the leaky ReLU as max(v, slope * v).  Everything else runs on the exact kernel (same results class).
     const bool slope_ok = d->pre_act != PRE_LRELU || (d->pre_slope >= 0.f && d->pre_slope <= 1.f);
-    if (want_prec == 1 && c->Mg >= 32 && d->tile_cfg < 0 && c->Cin % 16 == 0 && slope_ok) {
-        // split-bf16 plan: 16 channels per chunk, one MFMA k-step per tap; [m_tile][chunk*tap][piece][lane][8]
-        c->prec = 1;
+    if (want_prec >= 1 && c->Mg >= 32 && d->tile_cfg < 0 && c->Cin % 16 == 0 && slope_ok) {
+        // split plan: 16 channels per chunk, one MFMA k-step per tap; [m_tile][chunk*tap][piece][lane][8]
+        c->prec = want_prec;
+        const int NP = scheme_pieces(want_prec);
+        const bool f16 = scheme_is_f16(want_prec);
         c->cfg = (c->Mg <= 32) ? 2 : (c->Mg <= 64) ? 1 : 0;  // exact-kernel tile ids with the same block shapes
         const TileCfg t16 = tile_cfg(c->cfg);
         if (groups > 1 && c->Mg % t16.bm) return fail(PARROT_E_UNSUPPORTED, "conv_create: rows per group must be a multiple of the tile height");
         c->nchunks = (c->Cin + 15) / 16;
         c->n_it16 = c->nchunks * c->kk;
         const int mt16 = (c->M + t16.bm - 1) / t16.bm * (t16.bm / 32);
-        const size_t n16 = ((size_t)mt16 * c->n_it16 + 1) * 1536;  // 3 pieces x 64 lanes x 8 bf16 per step (+1 pad step)
+        const size_t step_h = (size_t)NP * 512;  // 16-bit words per step: NP pieces x 64 lanes x 8
+        const size_t n16 = ((size_t)mt16 * c->n_it16 + 1) * step_h;  // (+1 pad step)
         if (n16 * sizeof(uint16_t) >= ((size_t)1 << 31)) return fail(PARROT_E_UNSUPPORTED, "conv_create: packed weight stream larger than 2 GiB");
+        if (f16) c->wscale = f16_weight_scale(w, (size_t)d->c_in / groups * d->c_out * d->k);
         std::vector<uint16_t> pk16(n16, 0);
         for (int mt = 0; mt < mt16; ++mt)
             for (int ch = 0; ch < c->nchunks; ++ch)
                 for (int j = 0; j < c->kk; ++j) {
-                    uint16_t* g = pk16.data() + ((size_t)mt * c->n_it16 + (size_t)ch * c->kk + j) * 1536;
+                    uint16_t* g = pk16.data() + ((size_t)mt * c->n_it16 + (size_t)ch * c->kk + j) * step_h;
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
-                            const float v = wval(mt * 32 + (lane & 31), ch * 16 + 8 * (lane >> 5) + e, j);
-                            const uint16_t h1 = bf16_rn_host(v);
-                            const float r1 = v - bf16_to_f(h1);
-                            const uint16_t h2 = bf16_rn_host(r1);
-                            const uint16_t h3 = bf16_rn_host(r1 - bf16_to_f(h2));
-                            g[0 * 512 + lane * 8 + e] = h1;
-                            g[1 * 512 + lane * 8 + e] = h2;
-                            g[2 * 512 + lane * 8 + e] = h3;
+                            uint16_t h[3];
+                            split_weight(wval(mt * 32 + (lane & 31), ch * 16 + 8 * (lane >> 5) + e, j), want_prec, c->wscale, h);
+                            for (int pc = 0; pc < NP; ++pc) g[pc * 512 + lane * 8 + e] = h[pc];
                         }
                 }
         HIP_TRY(hipMalloc((void**)&c->wfrag16, n16 * sizeof(uint16_t)));
@@ -387,55 +464,45 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.epi = epi; p.div = div; p.u = c->u; p.u_inv16 = (65536 + c->u - 1) / c->u;
     p.groups = c->groups; p.Mg = c->Mg;
     p.row_len = row_len; p.row_len_mul = row_len_mul;
+    p.acc_scale = p.out_scale = 1.f;
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
     p.res_bstride = res_bstride > 0 ? res_bstride : p.y_bstride;
     int cfg = c->cfg;
     if (c->prec == 0 && (cfg == 0 || cfg == 3) && p.Ncols <= 64 && tile_cfg(4).ci == tile_cfg(cfg).ci) cfg = 4;  // same packing, narrower tile
-    if (c->prec == 1) {
+    if (c->prec >= 1) {
         p.wfrag = reinterpret_cast<const float*>(c->wfrag16);
         p.n_it = c->n_it16;
+        p.acc_scale = scheme_xs(c->prec) * c->wscale;
+        p.out_scale = 1.f / p.acc_scale;
         // 32-bit byte offsets inside one batch row (buffer addressing of the slab fetch)
         if ((double)c->Cin * Tin * 4.0 >= 2147483648.0) return fail(PARROT_E_UNSUPPORTED, "conv_run: batch row larger than 2 GiB");
     }
     TileCfg t = tile_cfg(cfg);
     int variant16 = 0;
-    if (c->prec == 1) {
+    if (c->prec >= 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
         // better (76 vs 61 TF on the qkv projection); every other layer is faster on the 64x64 wave tile
         // (and so are sequences of <= 64 steps -- the TTE encoder side -- which would leave half of a 128-column tile empty)
         variant16 = (cfg == 2) ? 3 : (cfg == 0 && (c->kk == 1 || p.Ncols <= 64)) ? 2 : cfg;
-        bf16x6_tile(variant16, t.bm, t.bn);
+        split_tile(variant16, t.bm, t.bn);
     }
     p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
     ProfRec rec{};
     if (g_prof_on) {
-        if (g_prof_pool.empty()) {
-            HIP_TRY(hipEventCreate(&rec.a));
-            HIP_TRY(hipEventCreate(&rec.b));
-        } else {
-            rec.a = g_prof_pool.back().first;
-            rec.b = g_prof_pool.back().second;
-            g_prof_pool.pop_back();
-        }
         // algorithmic work of the layer (real taps only; DESIGN.md "roofline accounting")
         const double macs = (double)B * c->d.c_out * c->Cin * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         const double elems = (double)B * ((double)c->d.c_in * Tin + (double)c->Cout * Tout * (1 + (res ? 1 : 0) + (epi != EPI_STORE ? 1 : 0)));
-        rec.cfg = (c->prec == 1) ? (variant16 >= 2 ? NUM_TILE_CFGS + 1 + variant16 : NUM_TILE_CFGS + cfg) : cfg;  // bf16x6 rows follow the exact ones
-        rec.flops = 2.0 * macs;
-        rec.bytes = 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k);
-        HIP_TRY(hipEventRecord(rec.a, s));
+        const int row = (c->prec >= 1) ? (variant16 >= 2 ? NUM_TILE_CFGS + 1 + variant16 : NUM_TILE_CFGS + cfg) : cfg;  // split rows follow the exact ones
+        TRY(prof_open(rec, row, 2.0 * macs, 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k), s));
     }
-    HIP_TRY(c->prec == 1 ? launch_conv_bf16x6(variant16, p, s) : (cfg == 6 ? launch_conv_mfma16(p, s) : launch_conv(cfg, p, s)));
+    HIP_TRY(c->prec >= 1 ? launch_conv_split(c->prec, variant16, p, s) : (cfg == 6 ? launch_conv_mfma16(p, s) : launch_conv(cfg, p, s)));
     if (c->d.act == ACT_TANH) {  // dense (B, Cout, Tout) output assumed for the tanh layers (conv_post)
         const size_t n = (size_t)B * c->Cout * Tout;
         hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n);
         HIP_TRY(hipGetLastError());
     }
-    if (g_prof_on) {
-        HIP_TRY(hipEventRecord(rec.b, s));
-        g_prof.push_back(rec);
-    }
+    if (g_prof_on) TRY(prof_close(rec, s));
     return PARROT_OK;
 }
 
@@ -486,8 +553,11 @@ struct parrot_voc {
     int* err = nullptr;
     std::unique_ptr<parrot_conv> conv_pre, conv_post;
     std::vector<std::unique_ptr<parrot_conv>> ups, rb;
-    std::vector<uint16_t*> rb_stream;  // per (stage, kernel): concatenated split-bf16 weight stream of the block (or null)
+    std::vector<uint16_t*> rb_stream;  // per (stage, kernel): concatenated split weight stream of the block (or null)
+    std::vector<float> rb_wsc;         // per resblock conv: weight scale inside that stream (fp16 schemes; else 1)
     int up_total = 1;
+    int scheme = 0;                    // PARROT_PREC_* captured at create (immutable afterwards)
+    int fused = 2;                     // fused-ResBlock mode captured at create
     ~parrot_voc() {
         for (uint16_t* q : rb_stream)
             if (q) (void)hipFree(q);
@@ -528,6 +598,14 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     if (w->n_rb != cfg->n_stages * cfg->n_kernels * per_rb) return fail(PARROT_E_INVALID, "voc_create: wrong number of resblock convs");
     std::unique_ptr<parrot_voc> v(new parrot_voc());
     v->cfg = *cfg;
+    v->scheme = default_prec();
+    v->fused = fused_mode();
+    // every upsampling stage must yield exactly T*u samples (k - u even: true for all HiFi-GAN configs): the workspace,
+    // the waveform buffer and the ragged-row bookkeeping are sized on that (the reference would return T*u + 1 otherwise)
+    for (int i = 0; i < cfg->n_stages; ++i) {
+        const int u = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
+        if (u <= 0 || k < u || ((k - u) & 1)) return fail(PARROT_E_UNSUPPORTED, "voc_create: upsample_kernel_size - upsample_rate must be even and >= 0");
+    }
     TRY(upload(&v->dict, w->dict, (size_t)cfg->num_embeddings * cfg->embedding_dim));
     if (cfg->multispkr) {
         if (!w->spkr) return fail(PARROT_E_INVALID, "voc_create: multispkr without spkr table");
@@ -560,23 +638,25 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
             }
         }
     }
-    // ResBlock1 blocks of the 32- and 16-channel stages under the split-bf16 scheme: one concatenated weight stream per
-    // block for the fused pair kernels (resblock_bf16x6.h), [conv][step][piece][lane][8 bf16] + padding for the prefetch past the end.
+    // ResBlock1 blocks of the 64-, 32- and 16-channel stages under a split scheme: one concatenated weight stream per
+    // block for the fused pair kernels (resblock_split.h), [conv][step][piece][lane][8 x 16 bit] + padding for the prefetch past the end.
     //   32 / 64 channels: the conv plans' own streams ([row tile][chunk * k + tap]);
     //   16 channels: packed here for the 16x16x32 MFMA (step = tap pair; lane = row l&15, channels 8(g&1).., tap 2*step + (g>>1)).
     v->rb_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
-    for (int i = 0; i < cfg->n_stages; ++i)
+    v->rb_wsc.assign((size_t)w->n_rb, 1.f);
+    const int NP = scheme_pieces(v->scheme);
+    for (int i = 0; i < cfg->n_stages && v->scheme >= 1; ++i)
         for (int j = 0; j < cfg->n_kernels; ++j) {
             const int rk = cfg->resblock_kernel_sizes[j], C = v->chan(i);
-            if (cfg->resblock_type != 1 || !resblock_bf16x6_has(C, rk) || per_rb > RBS_MAX_CONVS) continue;
+            if (cfg->resblock_type != 1 || !resblock_split_has(C, rk) || per_rb > RBS_MAX_CONVS) continue;
             const int base = (i * cfg->n_kernels + j) * per_rb;
-            const int steps = resblock_bf16x6_steps(C, rk);
-            const size_t step_b = 3072, conv_b = (size_t)steps * step_b;
+            const int steps = resblock_split_steps(C, rk);
+            const size_t step_b = (size_t)NP * 1024, conv_b = (size_t)steps * step_b;
             if (C >= 32) {  // the plans' streams are already [row tile][chunk * k + tap]
                 bool ok = true;
                 for (int q = 0; q < per_rb; ++q) {
                     const parrot_conv* pc = v->rb[base + q].get();
-                    ok = ok && pc->prec == 1 && pc->wfrag16 && pc->nchunks == C / 16 && (C / 32) * pc->n_it16 == steps && pc->M == C &&
+                    ok = ok && pc->prec == v->scheme && pc->wfrag16 && pc->nchunks == C / 16 && (C / 32) * pc->n_it16 == steps && pc->M == C &&
                          tile_cfg(pc->cfg).bm == C;
                 }
                 if (!ok) continue;
@@ -587,24 +667,23 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
                 v->rb_stream[(size_t)i * cfg->n_kernels + j] = st;
                 for (int q = 0; q <= per_rb; ++q)
                     HIP_TRY(hipMemcpy(reinterpret_cast<char*>(st) + q * conv_b, v->rb[base + (q < per_rb ? q : 0)]->wfrag16, conv_b, hipMemcpyDeviceToDevice));
+                for (int q = 0; q < per_rb; ++q) v->rb_wsc[base + q] = v->rb[base + q]->wscale;
             } else {
-                if (default_prec() != 1) continue;
-                std::vector<uint16_t> pk(((size_t)per_rb * steps + 2) * 1536, 0);
+                const size_t step_h = (size_t)NP * 512;
+                std::vector<uint16_t> pk(((size_t)per_rb * steps + 2) * step_h, 0);
                 for (int q = 0; q < per_rb; ++q) {
                     const float* wq = w->rb_w[base + q];  // (16, 16, rk)
+                    const float wsc = scheme_is_f16(v->scheme) ? f16_weight_scale(wq, (size_t)16 * 16 * rk) : 1.f;
+                    v->rb_wsc[base + q] = wsc;
                     for (int st = 0; st < steps; ++st) {
-                        uint16_t* g = pk.data() + ((size_t)q * steps + st) * 1536;
+                        uint16_t* g = pk.data() + ((size_t)q * steps + st) * step_h;
                         for (int lane = 0; lane < 64; ++lane)
                             for (int e = 0; e < 8; ++e) {
                                 const int row = lane & 15, ch = 8 * ((lane >> 4) & 1) + e, tap = 2 * st + (lane >> 5);
                                 const float val = tap < rk ? wq[((size_t)row * 16 + ch) * rk + tap] : 0.f;
-                                const uint16_t h1 = bf16_rn_host(val);
-                                const float r1 = val - bf16_to_f(h1);
-                                const uint16_t h2 = bf16_rn_host(r1);
-                                const uint16_t h3 = bf16_rn_host(r1 - bf16_to_f(h2));
-                                g[0 * 512 + lane * 8 + e] = h1;
-                                g[1 * 512 + lane * 8 + e] = h2;
-                                g[2 * 512 + lane * 8 + e] = h3;
+                                uint16_t h[3];
+                                split_weight(val, v->scheme, wsc, h);
+                                for (int pc = 0; pc < NP; ++pc) g[pc * 512 + lane * 8 + e] = h[pc];
                             }
                     }
                 }
@@ -636,24 +715,15 @@ static size_t voc_max_act(const parrot_voc* v, int B, int U) {
 // 16-channel stages.  Default 2: measured at B=64, the 16-channel kernel (16x16x4 MFMA, 1024-column windows) beats
 // the layer-by-layer path (5.3 vs 6.6 ms for stage 4) while the 32-channel one does not yet (10.5 vs 8.5 ms for
 // stage 3: 512-column windows pay 12-23 % halo recompute).  PARROT_FUSED / parrot_set_fused_resblocks override.
-static int g_fused = -1;
-static int fused_mode() {
-    if (g_fused < 0) {
-        const char* e = getenv("PARROT_FUSED");
-        g_fused = e ? atoi(e) : 2;
-        if (g_fused < 0 || g_fused > 2) g_fused = 2;
-    }
-    return g_fused;
-}
 extern "C" int parrot_set_fused_resblocks(int32_t mode) {
     if (mode < 0 || mode > 2) return fail(PARROT_E_INVALID, "set_fused_resblocks: mode must be 0, 1 or 2");
-    g_fused = mode;
+    g_fused.store(mode);
     return PARROT_OK;
 }
 static bool resblock_fusable(const parrot_voc* v, int stage, int j) {
     const parrot_voc_cfg& c = v->cfg;
     const int C = v->chan(stage), k = c.resblock_kernel_sizes[j];
-    const int fm = fused_mode();
+    const int fm = v->fused;
     if (fm == 0 || !(C == 16 || (C == 32 && fm == 1)) || !(k & 1)) return false;
     const int per_rb = (c.resblock_type == 1 ? 2 : 1) * c.n_dil;
     if (per_rb > RB_MAX_CONVS) return false;
@@ -709,7 +779,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
     const parrot_voc_cfg& c = v->cfg;
     const int per_rb = 2 * c.n_dil, k = c.resblock_kernel_sizes[j], C = v->chan(stage);
     const int base = (stage * c.n_kernels + j) * per_rb;
-    const int W = resblock_bf16x6_window(C), steps = resblock_bf16x6_steps(C, k);
+    const int W = resblock_split_window(C), steps = resblock_split_steps(C, k);
     const int hmax = rbs_hmax() * W / RBS_W;  // the same fraction of the window
     const uint16_t* stream = v->rb_stream[(size_t)stage * c.n_kernels + j];
     const float* src = x;
@@ -726,10 +796,11 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         ResblockSplitParams p{};
         p.x = src;
         p.y = last ? y : ((n_launch & 1) ? tmp_b : tmp_a);
-        p.wstream = stream + (size_t)m0 * steps * 1536;
+        p.wstream = stream + (size_t)m0 * steps * scheme_pieces(v->scheme) * 512;
         p.n_conv = m1 - m0;
         for (int q = m0; q < m1; ++q) {
             p.bias[q - m0] = v->rb[base + q]->bias;
+            p.wsc[q - m0] = v->rb_wsc[base + q];
             p.dil[q - m0] = v->rb[base + q]->dil;
         }
         p.T = T; p.B = B; p.H = H; p.k = k;
@@ -742,7 +813,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         ProfRec rec{};
         const double macs = (double)B * C * C * k * T * (m1 - m0);
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
-        HIP_TRY(launch_resblock_bf16x6(C, p, s));
+        HIP_TRY(launch_resblock_split(v->scheme, C, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
         src = p.y;
         m0 = m1;
@@ -826,7 +897,7 @@ extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, co
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
             // (the fused kernels address a batch row with 32-bit byte offsets: rows of 2 GiB and more go layer by layer)
-            if (fused_mode() != 0 && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
+            if (v->fused != 0 && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
                 TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, s, unit_lens, mul));
                 continue;
             }
@@ -882,6 +953,7 @@ struct parrot_tte {
     int* err = nullptr;
     std::unique_ptr<parrot_conv> dp0, dp1, dp_proj, head;
     std::vector<std::unique_ptr<FftLayer>> enc, dec;
+    std::vector<float*> dbg_enc, dbg_dec;  // parrot_tte_debug_stages (tests only)
     ~parrot_tte() {
         for (float* p : {pe, tok, spk, ln0_w, ln0_b, ln1_w, ln1_b})
             if (p) (void)hipFree(p);
@@ -1115,13 +1187,22 @@ extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const u
     hipLaunchKernelGGL(tte_embed_kernel, dim3((S + 63) / 64, (D + 63) / 64, B), dim3(256), 0, s, phones, t->tok, t->pe + (size_t)S * D,
                        w.x, S, D, c.vocab, t->err);
     HIP_TRY(hipGetLastError());
-    for (auto& L : t->enc) TRY(fft_block(t, L.get(), w, w.x, src_mask, B, S, s));
+    auto dbg = [&](const std::vector<float*>& v, size_t idx, const float* src, size_t n) -> int {
+        if (idx < v.size() && v[idx]) HIP_TRY(hipMemcpyAsync(v[idx], src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return PARROT_OK;
+    };
+    TRY(dbg(t->dbg_enc, 0, w.x, (size_t)B * D * S));
+    for (size_t n = 0; n < t->enc.size(); ++n) {
+        TRY(fft_block(t, t->enc[n].get(), w, w.x, src_mask, B, S, s));
+        TRY(dbg(t->dbg_enc, 1 + n, w.x, (size_t)B * D * S));
+    }
     if (t->spk) {
         const size_t total = (size_t)B * D * S;
         hipLaunchKernelGGL(add_channel_vec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w.x, speaker, t->spk, D, S,
                            c.n_speaker, total, t->err);
         HIP_TRY(hipGetLastError());
     }
+    TRY(dbg(t->dbg_enc, 1 + t->enc.size(), w.x, (size_t)B * D * S));
     HIP_TRY(hipMemcpyAsync(st.enc_out, w.x, (size_t)B * D * S * sizeof(float), hipMemcpyDeviceToDevice, s));
     // duration predictor (duration.py:29-48): conv -> relu -> LN -> conv(pad 1) -> relu -> LN -> linear
     const int NF = c.dp_filter;
@@ -1153,7 +1234,15 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
     hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, st.enc_out, st.cum, st.out_len,
                        t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D);
     HIP_TRY(hipGetLastError());
-    for (auto& Ly : t->dec) TRY(fft_block(t, Ly.get(), w, w.x, tgt_mask, B, L, s));
+    auto dbg = [&](size_t idx, const float* src, size_t n) -> int {
+        if (idx < t->dbg_dec.size() && t->dbg_dec[idx]) HIP_TRY(hipMemcpyAsync(t->dbg_dec[idx], src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return PARROT_OK;
+    };
+    TRY(dbg(0, w.x, (size_t)B * D * L));
+    for (size_t n = 0; n < t->dec.size(); ++n) {
+        TRY(fft_block(t, t->dec[n].get(), w, w.x, tgt_mask, B, L, s));
+        TRY(dbg(1 + n, w.x, (size_t)B * D * L));
+    }
     TRY(conv_launch(t->head.get(), w.x, nullptr, w.logits, B, L, EPI_STORE, 1.f, 0, 0, 0, s));
     hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, w.logits, ids, V, L);
     HIP_TRY(hipGetLastError());
@@ -1161,6 +1250,49 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
         hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((L + 63) / 64, (V + 63) / 64, B), dim3(256), 0, s, w.logits, logits, V, L);
         HIP_TRY(hipGetLastError());
     }
+    return PARROT_OK;
+}
+
+extern "C" int parrot_tte_debug_stages(parrot_tte_t* t, float* const* enc_ptrs, float* const* dec_ptrs) {
+    if (!t) return fail(PARROT_E_INVALID, "tte_debug_stages: null handle");
+    t->dbg_enc.clear();
+    t->dbg_dec.clear();
+    if (enc_ptrs) t->dbg_enc.assign(enc_ptrs, enc_ptrs + t->enc.size() + 2);
+    if (dec_ptrs) t->dbg_dec.assign(dec_ptrs, dec_ptrs + t->dec.size() + 1);
+    return PARROT_OK;
+}
+
+// length_regulator on its own (duration.py:6-24): channel-last in / out around the decoder's kernel
+extern "C" size_t parrot_length_regulator_workspace_bytes(int32_t B, int32_t S, int32_t D, int32_t L) {
+    if (B <= 0 || S <= 0 || D <= 0 || L < 0) return 0;
+    Arena a(nullptr, 0);
+    a.take<float>((size_t)B * D * S);
+    a.take<float>((size_t)B * D * std::max(L, 1));
+    a.take<float>((size_t)D);
+    a.take<int32_t>((size_t)B * S);
+    a.take<int32_t>((size_t)B);
+    return align_up(a.off, 256);
+}
+extern "C" int parrot_length_regulator(const float* seq, const int64_t* dur, int32_t B, int32_t S, int32_t D, int32_t L, float* out,
+                                       uint8_t* mask, int32_t* out_lens, void* ws, size_t ws_bytes, void* stream) {
+    if (!seq || !dur || !out || !mask || !out_lens || !ws) return fail(PARROT_E_INVALID, "length_regulator: null argument");
+    if (B <= 0 || S <= 0 || D <= 0 || L <= 0) return fail(PARROT_E_INVALID, "length_regulator: empty batch or L = 0");
+    hipStream_t s = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    float* seq_cf = a.take<float>((size_t)B * D * S);
+    float* out_cf = a.take<float>((size_t)B * D * L);
+    float* zero = a.take<float>((size_t)D);
+    int32_t* cum = a.take<int32_t>((size_t)B * S);
+    int32_t* lens = a.take<int32_t>((size_t)B);
+    if (!a.ok) return fail(PARROT_E_NOMEM, "length_regulator: workspace too small");
+    HIP_TRY(hipMemsetAsync(zero, 0, (size_t)D * sizeof(float), s));
+    // (B,S,D) -> (B,D,S): the transpose kernel with the roles of C and T swapped
+    hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((D + 63) / 64, (S + 63) / 64, B), dim3(256), 0, s, seq, seq_cf, S, D);
+    hipLaunchKernelGGL(dur_prefix_kernel, dim3(B), dim3(256), 0, s, dur, cum, lens, S);
+    hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, seq_cf, cum, lens, zero, out_cf, mask, S, L, D);
+    hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((L + 63) / 64, (D + 63) / 64, B), dim3(256), 0, s, out_cf, out, D, L);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_lens, lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return PARROT_OK;
 }
 

@@ -1,6 +1,8 @@
-// resblock_bf16x6.h -- HiFi-GAN ResBlock1 layer pairs (reference utils/vocoder/models.py:31-38) for the 32-channel
-// stage, fused per launch and evaluated with the split-bf16 scheme of conv_bf16x6.h (fp32 data, 6 bf16 MFMAs per
-// product, fp32 accumulate).
+// resblock_split.h -- HiFi-GAN ResBlock1 layer pairs (reference utils/vocoder/models.py:31-38) for the 16-, 32- and
+// 64-channel stages, fused per launch and evaluated with the split schemes of conv_split.h (fp32 data, a few 16-bit
+// MFMAs per product group, fp32 accumulate; template parameter SCH: 3 fp16 MFMAs / 6 bf16 MFMAs / 1 MFMA).
+// (Written below for three bf16 pieces; NP = SCH::NP pieces in general, pre-scaled operands for the fp16 schemes:
+//  the accumulator of conv m holds XS * wsc[m] * sum and is scaled back when it is consumed.)
 //
 // Layer by layer the 32-channel stage is bandwidth bound (every conv streams (B, 32, T) in, the residual in and
 // the result out: 3 passes per conv, 18 convs).  Here a workgroup owns a window of W = 384 columns:
@@ -24,7 +26,7 @@
 // order into ONE stream per ResBlock, so the in-place two-steps-ahead weight prefetch (see conv_bf16x6.h) runs
 // straight across conv boundaries.
 #pragma once
-#include "conv_bf16x6.h"
+#include "conv_split.h"
 
 namespace parrot {
 
@@ -35,6 +37,7 @@ struct ResblockSplitParams {
     float* y;                 // (B, C, T) output (MRF accumulator or an intermediate buffer)
     const uint16_t* wstream;  // this launch's first step in the ResBlock's concatenated weight stream (padded past the end for the prefetch)
     const float* bias[RBS_MAX_CONVS];
+    float wsc[RBS_MAX_CONVS];  // per-conv weight scale of the stream (power of two; 1 for the bf16 schemes)
     int dil[RBS_MAX_CONVS];
     int n_conv;               // convs in this launch (even: whole pairs)
     int k;                    // taps of every conv of the block
@@ -53,13 +56,14 @@ constexpr int RBS_W = 384;  // 32-channel window (the 64-channel kernel uses hal
 
 // NCH = channel chunks of 16: 2 -> 32 channels, 4 waves side by side (window 384);
 //                              4 -> 64 channels, 2 (row tiles) x 2 (column halves) waves (window 192).
-template <int NCH>
-__global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockSplitParams p) {
+template <class SCH, int NCH>
+__global__ __launch_bounds__(256, 2) void resblock_split_kernel(const ResblockSplitParams p) {
+    constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = 4 / WAVES_M, NTW = 3, W = WAVES_N * NTW * 32;
     const int K = p.k;
     constexpr int CH_BYTES = W * 32, PIECE_BYTES = NCH * CH_BYTES;  // [piece][chunk][col][16 ch] bf16
     static_assert(NCH == 2 || NCH == 4, "32 or 64 channels");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // 3 * PIECE_BYTES
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // NP * PIECE_BYTES
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -102,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
 
     // ---- accumulator tile -> operand buffer: (leaky ReLU,) sequence mask, 3-way split, two 8-byte stores per
     //      (tile, chunk, piece, row group): rows 8q+4g+{0..3} of this half are channels 16 (2 wm + q) + 8g + 4 half + {0..3}
-    auto write_p = [&](const f32x16 (&v)[NTW]) __attribute__((always_inline)) {
+    // `mul`: (power-of-two) factor taking v to the operand scale XS (v may be a scaled accumulator)
+    auto write_p = [&](const f32x16 (&v)[NTW], float mul) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int swz = (col[nt] >> 3) & 1;
@@ -110,22 +115,25 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    unsigned q0[2], q1[2], q2[2];
+                    unsigned qq[2][NPC];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         float v0 = v[nt][8 * q + 4 * g + 2 * e], v1 = v[nt][8 * q + 4 * g + 2 * e + 1];
+                        if constexpr (SCH::XS != 1.f) {
+                            v0 *= mul;
+                            v1 *= mul;
+                        }
                         v0 = max_nc(v0, v0 * p.slope);
                         v1 = max_nc(v1, v1 * p.slope);
                         if (edge) {
                             v0 = tok[nt] ? v0 : 0.f;
                             v1 = tok[nt] ? v1 : 0.f;
                         }
-                        split3_pk(v0, v1, q0[e], q1[e], q2[e]);
+                        SCH::split(v0, v1, qq[e]);
                     }
                     char* dst = smem_raw + (2 * wm + q) * CH_BYTES + col[nt] * 32 + ((g ^ swz) * 16) + 8 * half;
-                    *reinterpret_cast<uint2*>(dst) = uint2{q0[0], q0[1]};
-                    *reinterpret_cast<uint2*>(dst + PIECE_BYTES) = uint2{q1[0], q1[1]};
-                    *reinterpret_cast<uint2*>(dst + 2 * PIECE_BYTES) = uint2{q2[0], q2[1]};
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<uint2*>(dst + pc * PIECE_BYTES) = uint2{qq[0][pc], qq[1][pc]};
                 }
         }
     };
@@ -137,14 +145,14 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)w_hi << 32) | w_lo), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = lane * 16;
-    s16x8 A[2][3], Bv[2][NTW][3];
-    auto load_a_piece = [&](s16x8 (&a)[3], int pc, int gstep) __attribute__((always_inline)) {
-        a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, gstep * 3072, 0));
+    s16x8 A[2][NPC], Bv[2][NTW][NPC];
+    auto load_a_piece = [&](s16x8 (&a)[NPC], int pc, int gstep) __attribute__((always_inline)) {
+        a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, gstep * STEP_BYTES, 0));
     };
     const int conv_steps = WAVES_M * NCH * K;  // steps of one conv in the stream
     int gbase = wm * NCH * K;                  // this wave's first step of the current conv
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < NPC; ++pc) {
         load_a_piece(A[0], pc, gbase);      // (tap 0, chunk 0)
         load_a_piece(A[1], pc, gbase + K);  // (tap 0, chunk 1)
     }
@@ -155,19 +163,17 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
 #pragma unroll
             for (int r = 0; r < 16; ++r) R[nt][r] = tok[nt] ? R[nt][r] : 0.f;  // (already 0 from the range check; keeps the invariant explicit)
     }
-    write_p(R);
+    write_p(R, SCH::XS);
     __syncthreads();
 
-    constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
-    constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
     const int center = (K - 1) / 2;
-    auto load_b = [&](s16x8 (&bb)[NTW][3], int ch, int shift) __attribute__((always_inline)) {
+    auto load_b = [&](s16x8 (&bb)[NTW][NPC], int ch, int shift) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int cc = min(max(col[nt] + shift, 0), W - 1);  // clamped: only garbage columns ever read a clamped one
             const char* src = smem_raw + ch * CH_BYTES + cc * 32 + ((half ^ ((cc >> 3) & 1)) * 16);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bb[nt][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
+            for (int pc = 0; pc < NPC; ++pc) bb[nt][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
     };
     // one conv out of P into acc (initialised by the caller).  Tap loop; per tap NCH steps (input-channel chunk ch with
@@ -187,24 +193,25 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
                 else load_b(Bv[set ^ 1], 0, shift + dil);
                 const int nx = (ch + 2 < NCH) ? gbase + (ch + 2) * K + j : n0 + (ch + 2 - NCH) * K;  // two steps ahead
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[set][PA[t]]),
-                                                                          __builtin_bit_cast(bf16x8, Bv[set][nt][PB[t]]), acc[nt], 0, 0, 0);
-                    if (t == 0) load_a_piece(A[set], 2, nx);
-                    if (t == 2) load_a_piece(A[set], 1, nx);
-                    if (t == 5) load_a_piece(A[set], 0, nx);
+                    for (int nt = 0; nt < NTW; ++nt) acc[nt] = mfma32<SCH>(A[set][SCH::pa(t)], Bv[set][nt][SCH::pb(t)], acc[nt]);
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc)
+                        if (t == SCH::last_a(pc)) load_a_piece(A[set], pc, nx);
                 }
             }
-            // issue order: one memory instruction in the shadow of each MFMA (see conv_bf16x6.h)
+            // issue order: one memory instruction in the shadow of each MFMA (see conv_split.h)
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                int ds_left = 3 * NTW;
+                int ds_left = NPC * NTW;
 #pragma unroll
-                for (int m = 0; m < 6 * NTW; ++m) {
+                for (int m = 0; m < NTERM * NTW; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (m == NTW - 1 || m == 3 * NTW - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    bool refetch = false;
+#pragma unroll
+                    for (int pc = 1; pc < NPC; ++pc) refetch = refetch || (m == (SCH::last_a(pc) + 1) * NTW - 1);
+                    if (refetch) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     else if (ds_left > 0) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         --ds_left;
@@ -223,30 +230,35 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
 
     for (int m = 0; m < p.n_conv; m += 2) {
         float bv[16];
-        // h = conv_d(P) + b1
+        // h = conv_d(P) + b1   (accumulator scale s1 = XS * wsc[m])
+        const float s1 = SCH::XS * p.wsc[m], s2 = SCH::XS * p.wsc[m + 1];
         bias_rows(p.bias[m], bv);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = bv[r];
+            for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? bv[r] * s1 : bv[r];
         conv(p.dil[m]);
         __syncthreads();  // every wave is done reading P
-        write_p(acc);     // P = split(lrelu(h)), masked
+        write_p(acc, 1.f / p.wsc[m]);  // P = split(lrelu(h)), masked: acc / s1 * XS
         __syncthreads();
         // R = conv_1(P) + b2 + R
         bias_rows(p.bias[m + 1], bv);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = bv[r] + R[nt][r];
+            for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? (bv[r] + R[nt][r]) * s2 : bv[r] + R[nt][r];
         conv(p.dil[m + 1]);
+        const float i2 = 1.f / s2;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) R[nt][r] = (!edge || tok[nt]) ? acc[nt][r] : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const float v = (SCH::XS != 1.f) ? acc[nt][r] * i2 : acc[nt][r];
+                R[nt][r] = (!edge || tok[nt]) ? v : 0.f;
+            }
         if (m + 2 < p.n_conv) {
             __syncthreads();
-            write_p(R);
+            write_p(R, SCH::XS);
             __syncthreads();
         }
     }
@@ -292,12 +304,14 @@ __global__ __launch_bounds__(256, 2) void resblock_bf16x6_kernel(const ResblockS
 // the next pair's fragments are fetched during the current pair's MFMAs.
 constexpr int RBS16_W = 768;
 
-__global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const ResblockSplitParams p) {
+template <class SCH>
+__global__ __launch_bounds__(256, 2) void resblock16_split_kernel(const ResblockSplitParams p) {
+    constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16, NT = 12, W = RBS16_W, NP = NT / 2;
     const int K = p.k, S = (K + 1) / 2;  // tap pairs per conv (even: the host only takes k = 3, 7, 11)
     constexpr int PIECE_BYTES = W * 32;  // [piece][col][16 ch] bf16
     static_assert(4 * NT * 16 == W, "4 waves x NT tiles cover the window");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // 3 * PIECE_BYTES
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // NPC * PIECE_BYTES
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -326,28 +340,31 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
             for (int r = 0; r < 4; ++r) R[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, r * row_bytes, 0));
         }
     }
-    auto write_p = [&](const f32x4 (&v)[NT]) __attribute__((always_inline)) {
+    auto write_p = [&](const f32x4 (&v)[NT], float mul) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int c = col0 + nt * 16;
             const int t = t_base + c;
             const bool tk = t >= 0 && t < Tlim;
-            unsigned q0[2], q1[2], q2[2];
+            unsigned qq[2][NPC];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 float v0 = v[nt][2 * e], v1 = v[nt][2 * e + 1];
+                if constexpr (SCH::XS != 1.f) {
+                    v0 *= mul;
+                    v1 *= mul;
+                }
                 v0 = max_nc(v0, v0 * p.slope);
                 v1 = max_nc(v1, v1 * p.slope);
                 if (edge) {
                     v0 = tk ? v0 : 0.f;
                     v1 = tk ? v1 : 0.f;
                 }
-                split3_pk(v0, v1, q0[e], q1[e], q2[e]);
+                SCH::split(v0, v1, qq[e]);
             }
             char* dst = smem_raw + c * 32 + (((g4 >> 1) ^ ((c >> 2) & 1)) * 16) + 8 * (g4 & 1);
-            *reinterpret_cast<uint2*>(dst) = uint2{q0[0], q0[1]};
-            *reinterpret_cast<uint2*>(dst + PIECE_BYTES) = uint2{q1[0], q1[1]};
-            *reinterpret_cast<uint2*>(dst + 2 * PIECE_BYTES) = uint2{q2[0], q2[1]};
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<uint2*>(dst + pc * PIECE_BYTES) = uint2{qq[0][pc], qq[1][pc]};
         }
     };
 
@@ -356,30 +373,28 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)w_hi << 32) | w_lo), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = lane * 16;
-    s16x8 A[2][3], Bv[2][2][3];  // weights: two step sets; operands: two pair sets x two tiles x three pieces
-    auto load_a_piece = [&](s16x8 (&a)[3], int pc, int gstep) __attribute__((always_inline)) {
-        a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, gstep * 3072, 0));
+    s16x8 A[2][NPC], Bv[2][2][NPC];  // weights: two step sets; operands: two pair sets x two tiles x NPC pieces
+    auto load_a_piece = [&](s16x8 (&a)[NPC], int pc, int gstep) __attribute__((always_inline)) {
+        a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, gstep * STEP_BYTES, 0));
     };
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < NPC; ++pc) {
         load_a_piece(A[0], pc, 0);
         load_a_piece(A[1], pc, 1);
     }
-    write_p(R);
+    write_p(R, SCH::XS);
     __syncthreads();
 
-    constexpr int PA[6] = {2, 1, 1, 0, 0, 0};
-    constexpr int PB[6] = {0, 1, 0, 2, 1, 0};
     const int center = (K - 1) / 2;
     int gstep = 0;
     // fragments of tile pair pr at step s: column + (2s + tap parity - center) * dil, clamped to the window
-    auto load_b = [&](s16x8 (&bb)[2][3], int pr, int shift) __attribute__((always_inline)) {
+    auto load_b = [&](s16x8 (&bb)[2][NPC], int pr, int shift) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int cc = min(max(col0 + (2 * pr + q) * 16 + shift, 0), W - 1);
             const char* src = smem_raw + cc * 32 + (((g4 & 1) ^ ((cc >> 2) & 1)) * 16);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bb[q][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
+            for (int pc = 0; pc < NPC; ++pc) bb[q][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
     };
     // one conv: loop over step pairs (weight set 0 / 1), six tile pairs per step alternating the operand sets
@@ -396,29 +411,31 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
                     if (pr + 1 < NP) load_b(Bv[cur ^ 1], pr + 1, tpd + 2 * s * dil);
                     else load_b(Bv[cur ^ 1], 0, tpd + 2 * (s + 1) * dil);  // (after the last step: discarded)
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) {
+                    for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q)
-                            acc[2 * pr + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[sub][PA[t]]),
-                                                                                      __builtin_bit_cast(bf16x8, Bv[cur][q][PB[t]]), acc[2 * pr + q], 0, 0, 0);
+                            acc[2 * pr + q] = mfma16<SCH>(A[sub][SCH::pa(t)], Bv[cur][q][SCH::pb(t)], acc[2 * pr + q]);
                         if (pr == NP - 1) {  // last pair of the step: each weight piece is dead after its last term
-                            if (t == 0) load_a_piece(A[sub], 2, gstep + s + 2);
-                            if (t == 2) load_a_piece(A[sub], 1, gstep + s + 2);
-                            if (t == 5) load_a_piece(A[sub], 0, gstep + s + 2);
+#pragma unroll
+                            for (int pc = 0; pc < NPC; ++pc)
+                                if (t == SCH::last_a(pc)) load_a_piece(A[sub], pc, gstep + s + 2);
                         }
                     }
                 }
             }
-            // issue order: the next pair's six fragment reads in the shadow of the first six MFMAs of each pair
+            // issue order: the next pair's fragment reads in the shadow of the first MFMAs of each pair
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
-                    for (int m = 0; m < 12; ++m) {
+                    for (int m = 0; m < 2 * NTERM; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (pr == NP - 1 && (m == 1 || m == 5 || m == 11)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        if (m < 2 * NPC) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        bool refetch = false;
+#pragma unroll
+                        for (int pc = 0; pc < NPC; ++pc) refetch = refetch || (m == 2 * (SCH::last_a(pc) + 1) - 1);
+                        if (pr == NP - 1 && refetch) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -427,33 +444,35 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
 
     for (int m = 0; m < p.n_conv; m += 2) {
         float bv[4];
+        const float s1 = SCH::XS * p.wsc[m], s2 = SCH::XS * p.wsc[m + 1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = p.bias[m][4 * g4 + r];
+        for (int r = 0; r < 4; ++r) bv[r] = (SCH::XS != 1.f) ? p.bias[m][4 * g4 + r] * s1 : p.bias[m][4 * g4 + r];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[nt][r] = bv[r];
         conv(p.dil[m]);
         __syncthreads();
-        write_p(acc);
+        write_p(acc, 1.f / p.wsc[m]);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + 1][4 * g4 + r];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nt][r] = bv[r] + R[nt][r];
+            for (int r = 0; r < 4; ++r) acc[nt][r] = (SCH::XS != 1.f) ? (bv[r] + R[nt][r]) * s2 : bv[r] + R[nt][r];
         conv(p.dil[m + 1]);
+        const float i2 = 1.f / s2;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int t = t_base + col0 + nt * 16;
             const bool tk = !edge || (t >= 0 && t < Tlim);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R[nt][r] = tk ? acc[nt][r] : 0.f;
+            for (int r = 0; r < 4; ++r) R[nt][r] = tk ? ((SCH::XS != 1.f) ? acc[nt][r] * i2 : acc[nt][r]) : 0.f;
         }
         if (m + 2 < p.n_conv) {
             __syncthreads();
-            write_p(R);
+            write_p(R, SCH::XS);
             __syncthreads();
         }
     }
@@ -480,9 +499,10 @@ __global__ __launch_bounds__(256, 2) void resblock16_bf16x6_kernel(const Resbloc
     }
 }
 
-inline hipError_t launch_resblock_bf16x6(int C, const ResblockSplitParams& p, hipStream_t s) {
-    const size_t lds = (size_t)3 * 2 * RBS_W * 32;  // the same 72 KiB for every channel count
-    auto kern = (C == 16) ? resblock16_bf16x6_kernel : (C == 64) ? resblock_bf16x6_kernel<4> : resblock_bf16x6_kernel<2>;
+template <class SCH>
+inline hipError_t launch_resblock_split_s(int C, const ResblockSplitParams& p, hipStream_t s) {
+    const size_t lds = (size_t)SCH::NP * 2 * RBS_W * 32;  // the same for every channel count (72 KiB with three pieces)
+    auto kern = (C == 16) ? resblock16_split_kernel<SCH> : (C == 64) ? resblock_split_kernel<SCH, 4> : resblock_split_kernel<SCH, 2>;
     static bool attr_set[3] = {false, false, false};
     const int slot = (C == 16) ? 0 : (C == 64) ? 2 : 1;
     if (!attr_set[slot]) {
@@ -493,12 +513,21 @@ inline hipError_t launch_resblock_bf16x6(int C, const ResblockSplitParams& p, hi
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
     return hipGetLastError();
 }
+inline hipError_t launch_resblock_split(int scheme, int C, const ResblockSplitParams& p, hipStream_t s) {
+    switch (scheme) {
+        case SchBf16x6::ID: return launch_resblock_split_s<SchBf16x6>(C, p, s);
+        case SchF16x3::ID: return launch_resblock_split_s<SchF16x3>(C, p, s);
+        case SchBf16::ID: return launch_resblock_split_s<SchBf16>(C, p, s);
+        case SchF16::ID: return launch_resblock_split_s<SchF16>(C, p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
 // odd tap counts with (k + 1) / 2 even; at 64 channels the 192-column window loses too much to the halo of k = 11
-inline bool resblock_bf16x6_has(int C, int k) {
+inline bool resblock_split_has(int C, int k) {
     if (C == 64) return k == 3 || k == 7;
     return (C == 32 || C == 16) && (k == 3 || k == 7 || k == 11);
 }
-inline int resblock_bf16x6_window(int C) { return C == 16 ? RBS16_W : C == 64 ? RBS_W / 2 : RBS_W; }
-inline int resblock_bf16x6_steps(int C, int k) { return C == 16 ? (k + 1) / 2 : (C / 32) * (C / 16) * k; }  // weight steps per conv
+inline int resblock_split_window(int C) { return C == 16 ? RBS16_W : C == 64 ? RBS_W / 2 : RBS_W; }
+inline int resblock_split_steps(int C, int k) { return C == 16 ? (k + 1) / 2 : (C / 32) * (C / 16) * k; }  // weight steps per conv
 
 }  // namespace parrot

@@ -20,6 +20,7 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("PARROT_DIST_BACKEND") or backend
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -28,6 +29,13 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def local_device(local_rank: int) -> torch.device:
+    """cuda:<local_rank>, wrapped onto the devices this process can see: with fewer GPUs than ranks (the 2-ranks-on-one-GPU
+    test of the N>1 path; RCCL refuses two ranks on one device, so that test sets PARROT_DIST_BACKEND=gloo) ranks share."""
+    n = torch.cuda.device_count()
+    return torch.device("cuda", local_rank % n if n else local_rank)
 
 
 def shard_rows(n_rows: int, rank: int, world: int) -> slice:
@@ -45,17 +53,88 @@ def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[s
     return {k: (v[sl] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v) for k, v in batch.items()}
 
 
-def gather_waveforms(wav: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
-    """Gather equal-shaped (b, 1, n) waveform shards to rank `dst` in rank order -> (world*b, 1, n) there,
-    None elsewhere.  One RCCL gather: every peer has its own xGMI link to the root, 21 MB per shard."""
+_meta_group = None          # gloo side group for host-side shape exchange (no device sync)
+_gather_buf: Dict[tuple, torch.Tensor] = {}
+
+
+def _meta_pg():
+    """A CPU (gloo) process group beside the RCCL one: shapes are host integers, and exchanging them through the device
+    backend would cost a stream synchronisation per step."""
+    global _meta_group
+    if dist.get_backend() == "gloo":
+        return None  # the default group already is one
+    if _meta_group is None:
+        _meta_group = dist.new_group(backend="gloo")
+    return _meta_group
+
+
+def gather_waveforms(wav: torch.Tensor, dst: int = 0, equal_shapes: bool = False,
+                     n_samples: Optional[torch.Tensor] = None):
+    """Gather (b_r, 1, n_r) waveform shards to rank ``dst`` in rank order -> (sum b_r, 1, max n_r) there, None elsewhere.
+    One RCCL gather (grouped send/recv: every peer has its own xGMI link to the root; 21 MB per shard at B=64 x 256
+    units) into ONE receive buffer that is allocated once per shape and reused -- the returned tensor is a view of it and
+    is overwritten by the next call with the same shapes; the counterpart of the result queue of reference
+    utils/vocoder/inference.py:201-205,255.
+
+    Shards may differ in rows (B % world != 0) and in length (L = max over the shard's rows is data dependent): the
+    (b_r, n_r) pairs -- host integers -- are exchanged first over a gloo side group, shorter shards are zero-padded to
+    the longest.  ``equal_shapes=True`` skips that exchange when the caller knows all shards agree (fixed-length
+    workloads).  With ``n_samples`` ((b_r,) valid samples per row) the root gets ``(wav, n_samples_all)``."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return wav
+        return wav if n_samples is None else (wav, n_samples)
     world, rank = dist.get_world_size(), dist.get_rank()
-    out: Optional[List[torch.Tensor]] = None
+    b, n = int(wav.shape[0]), int(wav.shape[-1])
+    if equal_shapes:
+        shapes = [(b, n)] * world
+    else:
+        mine = torch.tensor([b, n], dtype=torch.int64)
+        allsh = [torch.empty(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allsh, mine, group=_meta_pg())
+        shapes = [(int(t[0]), int(t[1])) for t in allsh]
+    bmax, nmax = max(s[0] for s in shapes), max(s[1] for s in shapes)
+    host_staged = dist.get_backend() == "gloo" and wav.device.type != "cpu"  # gloo's gather takes CPU tensors only
+    send = wav.reshape(b, n)
+    if (b, n) != (bmax, nmax):
+        send = torch.zeros((bmax, nmax), dtype=wav.dtype, device=wav.device)
+        send[:b, :n] = wav.reshape(b, n)
+    send = send.contiguous()
+    if host_staged:
+        send = send.cpu()
+    out = None
     if rank == dst:
-        out = [torch.empty_like(wav) for _ in range(world)]
-    dist.gather(wav.contiguous(), out, dst=dst)
-    return torch.cat(out, dim=0) if rank == dst else None
+        key = (world, bmax, nmax, wav.dtype, str(send.device))
+        if key not in _gather_buf:
+            _gather_buf.clear()  # one live shape: do not pin the memory of shapes long gone
+            _gather_buf[key] = torch.empty((world, bmax, nmax), dtype=wav.dtype, device=send.device)
+        out = list(_gather_buf[key].unbind(0))
+    dist.gather(send, out, dst=dst)
+    lens_all = None
+    if n_samples is not None:
+        lens_all = [torch.empty(s[0], dtype=torch.int64) for s in shapes] if rank == dst else None
+        lens_all = _gather_host_rows(n_samples.to("cpu", torch.int64), lens_all, shapes, dst)
+    if rank != dst:
+        return None
+    buf = _gather_buf[key]
+    if all(s[0] == bmax for s in shapes):
+        res = buf.view(world * bmax, 1, nmax)          # no copy: rows already in rank order
+    else:
+        res = torch.cat([buf[r, : shapes[r][0]] for r in range(world)], dim=0).unsqueeze(1)
+    if host_staged:
+        res = res.to(wav.device)
+    return res if n_samples is None else (res, lens_all)
+
+
+def _gather_host_rows(mine: torch.Tensor, out, shapes, dst):
+    """Ragged CPU int64 rows to ``dst`` over the gloo side group (padded to the longest shard)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    bmax = max(s[0] for s in shapes)
+    pad = torch.zeros(bmax, dtype=torch.int64)
+    pad[: mine.numel()] = mine
+    recv = [torch.empty(bmax, dtype=torch.int64) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, recv, dst=dst, group=_meta_pg())
+    if rank != dst:
+        return None
+    return torch.cat([recv[r][: shapes[r][0]] for r in range(world)])
 
 
 def gather_ragged_rows(rows: List[List[int]], dst: int = 0) -> Optional[List[List[int]]]:

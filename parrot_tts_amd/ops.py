@@ -14,17 +14,21 @@ from . import _lib
 PRE_NONE, PRE_LRELU = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 EPI_STORE, EPI_ADD, EPI_ADD_DIV = 0, 1, 2
-PREC_F32, PREC_BF16X6 = 0, 1
+PREC_F32, PREC_BF16X6, PREC_F16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3, 4
+PREC_NAMES = {"f32": PREC_F32, "bf16x6": PREC_BF16X6, "f16x3": PREC_F16X3, "bf16": PREC_BF16, "f16": PREC_F16}
+PREC_DEFAULT = PREC_F16X3
 
 
 def set_default_precision(prec: int) -> None:
-    """Library-wide default for handles created afterwards (PREC_F32 exact fp32 MFMA, PREC_BF16X6 split-bf16)."""
+    """Library-wide default for handles created afterwards (include/parrot_hip.h PARROT_PREC_*): PREC_F32 exact fp32
+    MFMA, PREC_F16X3 (default) / PREC_BF16X6 split schemes with fp32-class error, PREC_BF16 / PREC_F16 single-MFMA
+    reduced precision."""
     _lib.check(_lib.lib().parrot_set_default_precision(int(prec)))
 
 
 def set_fused_resblocks(mode: int) -> None:
-    """ResBlocks through the fused LDS-resident kernels (csrc/resblock_fused.h): 0 off, 1 for 16- and 32-channel
-    stages, 2 for 16-channel stages only (library default)."""
+    """ResBlocks through the fused LDS-resident kernels: 0 off, 1 every eligible stage, 2 all but the exact-fp32
+    32-channel kernel (library default).  Applies to handles created afterwards."""
     _lib.check(_lib.lib().parrot_set_fused_resblocks(int(mode)))
 
 
@@ -39,6 +43,13 @@ def dptr(t: Optional[torch.Tensor]) -> C.c_void_p:
 def require_cuda(t: torch.Tensor, name: str) -> None:
     if t.device.type != "cuda":
         raise RuntimeError(f"parrot_tts_amd: `{name}` must live on the GPU (got {t.device}); there is no CPU fallback")
+
+
+def param_fingerprint(module) -> tuple:
+    """Identity + version of every parameter / buffer of ``module``: changes whenever a tensor is replaced, moved or
+    written in place (``load_state_dict`` through ANY parent module copies in place and bumps ``_version``).  The HIP
+    handle caches packed copies of the weights, so the shims compare this before every forward and rebuild on mismatch."""
+    return tuple((id(t), t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
 
 
 def selftest() -> None:
@@ -97,3 +108,25 @@ def wav_to_int16(wav: torch.Tensor) -> torch.Tensor:
     out = torch.empty(w.shape, device=w.device, dtype=torch.int16)
     _lib.check(_lib.lib().parrot_wav_to_int16(dptr(w), dptr(out), w.numel(), stream_ptr(w.device)))
     return out
+
+
+def length_regulator(seq: torch.Tensor, dur: torch.Tensor):
+    """``length_regulator`` of reference modules/duration.py:6-24 on the HIP kernel the TTE decoder uses: seq (B,S,D) f32,
+    dur (B,S) int64 -> (expanded (B,L,D) zero-padded to L = max row sum, tgt_mask (B,L) bool with the ``ids <= len`` rule
+    of modules/data.py:18, out_lens list).  L is read back to the host like the reference does (duration.py:10)."""
+    require_cuda(seq, "seq")
+    seq = seq.to(torch.float32).contiguous()
+    dur = dur.to(seq.device, torch.int64).contiguous()
+    B, S, D = seq.shape
+    L = int(torch.clamp(dur, min=0).sum(dim=1).max())  # the reference's own host sync
+    if L <= 0:
+        raise ValueError("length_regulator: every duration is zero (the reference fails downstream on an empty sequence)")
+    lib = _lib.lib()
+    ws = torch.empty(lib.parrot_length_regulator_workspace_bytes(B, S, D, L), dtype=torch.uint8, device=seq.device)
+    out = torch.empty((B, L, D), dtype=torch.float32, device=seq.device)
+    mask = torch.empty((B, L), dtype=torch.uint8, device=seq.device)
+    lens = torch.empty((B,), dtype=torch.int32, device=seq.device)
+    with torch.cuda.device(seq.device):
+        _lib.check(lib.parrot_length_regulator(dptr(seq), dptr(dur), B, S, D, L, dptr(out), dptr(mask), dptr(lens), dptr(ws), ws.numel(),
+                                               stream_ptr(seq.device)))
+    return out, mask.bool(), lens.cpu().tolist()

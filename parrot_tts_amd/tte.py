@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import dptr, require_cuda, stream_ptr
+from .ops import dptr, param_fingerprint, require_cuda, stream_ptr
 from .synth import sinusoid_table
 
 
@@ -99,6 +99,11 @@ class Parrot(nn.Module):
             _attach(self, key, t)
         self._handle: Optional[C.c_void_p] = None
         self._handle_device = None
+        self._handle_fp = None
+        # torch's load_state_dict recurses through _load_from_state_dict and never calls a CHILD's load_state_dict
+        # override, so a reload through any wrapper (LitParrot, nn.Sequential ...) is caught here: the post hook runs
+        # for every module of the tree, and _current_handle() also compares the parameters' version fingerprint.
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
     # ---- parameter bookkeeping ----------------------------------------------------------------
     def _invalidate(self):
@@ -106,9 +111,14 @@ class Parrot(nn.Module):
             _lib.lib().parrot_tte_destroy(self._handle)
         self._handle = None
 
-    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        self._invalidate()
-        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+    def _current_handle(self, dev):
+        """The packed-weight handle for ``dev``, rebuilt when any parameter was replaced, moved or written in place."""
+        fp = param_fingerprint(self)
+        if self._handle is None or self._handle_device != dev or self._handle_fp != fp:
+            self._invalidate()
+            self._build(dev)
+            self._handle_fp = fp
+        return self._handle
 
     def _apply(self, fn, recurse=True):
         self._invalidate()
@@ -162,9 +172,7 @@ class Parrot(nn.Module):
         phones = batch["phones"]
         require_cuda(phones, "batch['phones']")
         dev = phones.device
-        if self._handle is None or self._handle_device != dev:
-            self._invalidate()
-            self._build(dev)
+        self._current_handle(dev)
         lib = _lib.lib()
         phones = phones.to(torch.int64).contiguous()
         B, S = phones.shape
@@ -199,6 +207,36 @@ class Parrot(nn.Module):
                 raise
         return {"ids": ids, "tgt_mask": tgt.bool(), "log_dur": log_dur, "dur": dur, "lens": lens_h, "logits": logits,
                 "src_mask": src_mask}
+
+    @torch.no_grad()
+    def forward_stages(self, batch) -> dict:
+        """Tests / error localisation: one inference forward that also returns the activation after every stage in the
+        reference's (B, T, D) layout, keyed like the oracle's ``return_stages`` ("emb", "enc0".., "enc_out", "dec_in",
+        "dec0"..) -- plus everything ``forward`` returns."""
+        dev = batch["phones"].device
+        self._current_handle(dev)
+        lib = _lib.lib()
+        tr = self.data_config["transformer"]
+        ne, nd = tr["encoder"]["n_layer"], tr["decoder"]["n_layer"]
+        B, S = batch["phones"].shape
+        D = self.d_model
+        enc = [torch.empty((B, D, S), dtype=torch.float32, device=dev) for _ in range(ne + 2)]
+        enc_ptrs = (C.c_void_p * (ne + 2))(*[C.c_void_p(t.data_ptr()) for t in enc])
+        _lib.check(lib.parrot_tte_debug_stages(self._handle, enc_ptrs, None))
+        try:
+            L = int(self._run(batch, want_logits=False)["lens"].max())  # pass 1: encoder stages (+ the expanded length)
+            dec = [torch.empty((B, D, L), dtype=torch.float32, device=dev) for _ in range(nd + 1)]
+            dec_ptrs = (C.c_void_p * (nd + 1))(*[C.c_void_p(t.data_ptr()) for t in dec])
+            _lib.check(lib.parrot_tte_debug_stages(self._handle, enc_ptrs, dec_ptrs))
+            r = self._run(batch, want_logits=True)
+            torch.cuda.synchronize(dev)
+        finally:
+            _lib.check(lib.parrot_tte_debug_stages(self._handle, None, None))
+        names = ["emb"] + [f"enc{n}" for n in range(ne)] + ["enc_out"]
+        st = {k: t.transpose(1, 2).contiguous() for k, t in zip(names, enc)}
+        st.update({k: t.transpose(1, 2).contiguous() for k, t in zip(["dec_in"] + [f"dec{n}" for n in range(nd)], dec)})
+        r["stages"] = st
+        return r
 
     def forward(self, batch, inference=False):
         if inference is not True:

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import dptr, require_cuda, stream_ptr
+from .ops import dptr, param_fingerprint, require_cuda, stream_ptr
 
 
 class AttrDict(dict):
@@ -136,7 +136,11 @@ class CodeGenerator(nn.Module):
 
         self._handle: Optional[C.c_void_p] = None
         self._handle_device = None
+        self._handle_fp = None
         self._ws: Dict[tuple, torch.Tensor] = {}
+        # a reload through a parent module never reaches a child's load_state_dict override: invalidate from the post
+        # hook torch runs for every module of the tree, and compare the parameter fingerprint before each forward
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
     # ---- parameter bookkeeping ----------------------------------------------------------------
     def _invalidate(self):
@@ -144,9 +148,14 @@ class CodeGenerator(nn.Module):
             _lib.lib().parrot_voc_destroy(self._handle)
         self._handle, self._ws = None, {}
 
-    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        self._invalidate()
-        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+    def _current_handle(self, dev):
+        """The packed-weight handle for ``dev``, rebuilt when any parameter was replaced, moved or written in place."""
+        fp = param_fingerprint(self)
+        if self._handle is None or self._handle_device != dev or self._handle_fp != fp:
+            self._invalidate()
+            self._build(dev)
+            self._handle_fp = fp
+        return self._handle
 
     def _apply(self, fn, recurse=True):
         self._invalidate()
@@ -235,9 +244,7 @@ class CodeGenerator(nn.Module):
             spkr = kwargs["spkr"].to(dev).reshape(-1).contiguous()
             if spkr.dtype != torch.int64 or spkr.numel() != code.shape[0]:
                 raise ValueError("spkr must be a LongTensor of shape (B, 1)")
-        if self._handle is None or self._handle_device != dev:
-            self._invalidate()
-            self._build(dev)
+        self._current_handle(dev)
         code = code.contiguous()
         B, U = code.shape
         lens32 = None

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_basics(lib):
-    assert lib.parrot_abi_version() == 1
+    assert lib.parrot_abi_version() == 2
     assert lib.parrot_conv_num_tile_cfgs() >= 3
     assert isinstance(lib.parrot_last_error(), bytes)
     # argument validation happens before any HIP call
@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
     int (*run)(parrot_conv_t*, const float*, const float*, float*, int32_t, int32_t, int32_t, float, void*) =
         (int (*)(parrot_conv_t*, const float*, const float*, float*, int32_t, int32_t, int32_t, float, void*))dlsym(h, "parrot_conv_run");
     if (!ver || !err || !run) return 3;
-    if (ver() != 1) return 4;
+    if (ver() != PARROT_ABI_VERSION) return 4;
     if (run(NULL, NULL, NULL, NULL, 1, 1, 0, 1.0f, NULL) != PARROT_E_INVALID) return 5;
     if (!strstr(err(), "null")) return 6;
     printf("ok\\n");

@@ -39,6 +39,29 @@ def _worker(rank, world, port, out_dir):
         open(os.path.join(out_dir, "ok"), "w").write("ok")
     else:
         assert g is None and gr is None
+    # ragged shards: 5 rows over 2 ranks (3 + 2) and a data-dependent length per shard (equal-shape
+    # receive buffers would hang / corrupt here); twice, so the second call reuses the preallocated receive buffer
+    for rep in range(2):
+        sl5 = pdist.shard_rows(5, r, w)
+        n_r = 12 + 4 * r + rep
+        rowsv = torch.arange(sl5.start, sl5.stop, dtype=torch.float32)
+        wav_r = (rowsv[:, None, None] * 100 + torch.arange(float(n_r))[None, None, :]).contiguous()
+        lens_r = torch.arange(sl5.start, sl5.stop) + 3
+        got = pdist.gather_waveforms(wav_r, dst=0, n_samples=lens_r)
+        if r == 0:
+            gw, gl = got
+            nmax = 12 + 4 * (w - 1) + rep
+            assert gw.shape == (5, 1, nmax) and gl.tolist() == [3, 4, 5, 6, 7]
+            for row in range(5):
+                rk = 0 if row < 3 else 1
+                n_row = 12 + 4 * rk + rep
+                assert torch.equal(gw[row, 0, :n_row], row * 100 + torch.arange(float(n_row)))
+                assert float(gw[row, 0, n_row:].abs().sum()) == 0.0  # shorter shards are zero-padded
+        else:
+            assert got is None
+    ge = pdist.gather_waveforms(wav, dst=0, equal_shapes=True)  # fixed-length workloads skip the shape exchange
+    if r == 0:
+        assert torch.equal(ge, want)
     dist.barrier()
     dist.destroy_process_group()
 

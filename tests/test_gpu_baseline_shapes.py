@@ -1,0 +1,263 @@
+"""GPU parity at BASELINE.json's own shapes (configs[1], [2], [4]) and for the rows round 1 left thin: every one of the
+64 x 256 unit ids against the oracle, the B=32 vocoder-only batch, the full-size long-form batch (chunk-streamed and whole),
+the adversarial length-regulator golden through the HIP kernel, ResBlock2 at full width, non-default model configs and
+the reduced-precision (bf16 / fp16 single-MFMA) operating point by SNR.  Same tolerances as tests/test_gpu_parity.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import parrot_oracle as O  # noqa: E402
+from parrot_tts_amd import ops, synth  # noqa: E402
+from parrot_tts_amd.tte import Parrot  # noqa: E402
+from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
+
+DEV = "cuda:0"
+torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
+
+
+def _report(**kw):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+@pytest.fixture(params=["f32", "bf16x6", "f16x3"])
+def prec(request):
+    ops.set_default_precision(ops.PREC_NAMES[request.param])
+    yield request.param
+    ops.set_default_precision(ops.PREC_DEFAULT)
+
+
+def _parrot(cfg, vocab, n_spk, sd, tmp_path):
+    cfg = synth.clone_config(cfg)
+    cfg["path"]["root_path"] = str(tmp_path)
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({f"s{i}": i for i in range(n_spk)}, f)
+    m = Parrot(cfg, vocab, 0)
+    m.load_state_dict(sd)
+    return m.eval().to(DEV)
+
+
+def _gen(h, sd):
+    g = CodeGenerator(AttrDict(h))
+    g.load_state_dict(sd)
+    return g.eval().to(DEV)
+
+
+def _tte_vs_oracle(model, tsd, cfg, batch, tag, prec):
+    """All ids of the batch against the oracle run of the SAME padded batch; returns the report row."""
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    with torch.no_grad():
+        ref = O.tte_forward(tsd, cfg, batch)
+    logits, _, tgt_mask, log_dur = model(gb, inference=True)
+    ids = model.infer_dense(gb)["ids"].cpu()
+    m = ref["tgt_mask"]
+    assert torch.equal(tgt_mask.cpu(), m)
+    assert float((log_dur.cpu() - ref["log_dur"]).abs().max()) <= 2e-5
+    err = (logits.cpu() - ref["logits"]).abs().amax(-1)            # per position
+    top2 = torch.topk(ref["logits"], 2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    ref_ids = torch.argmax(ref["logits"], -1)
+    decided = m & (margin > 1e-4)
+    row = dict(test="tte_all_ids_vs_oracle", shape=tag, precision=prec, positions=int(m.sum()), decided=int(decided.sum()),
+               mismatches_all=int((ids != ref_ids)[m].sum()), logits_max_abs_err=float(err[m].max()),
+               min_margin=float(margin[m].min()), worst_margin_minus_2err=float((margin - 2 * err)[m].min()))
+    _report(**row)
+    assert float(err[m].max()) <= 1e-4
+    assert torch.equal(ids[decided], ref_ids[decided]), "unit ids differ from the reference where the top-2 margin decides"
+    assert decided[m].float().mean() > 0.999
+    return row
+
+
+def test_config3_every_one_of_the_64x256_unit_ids_matches_the_oracle(tmp_path, prec):
+    """BASELINE configs[2] shape (B=64, S=64, forced duration 4 -> L=256), full-size TTE: ALL 16 384 ids against the
+    reference restatement run on the same padded batch (north_star: bit-exact ids)."""
+    cfg = synth.default_tte_config()
+    vocab, n_spk, B, S = 300, 10, 64, 64
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=42, forced_duration=4)
+    model = _parrot(cfg, vocab, n_spk, tsd, tmp_path)
+    row = _tte_vs_oracle(model, tsd, cfg, synth.synth_tte_batch(B, S, vocab, n_spk, seed=0), "B64xS64xL256", prec)
+    assert row["positions"] == 64 * 256
+
+
+def test_config2_vocoder_only_batch32_x_256_units(prec):
+    """BASELINE configs[1]: HiFi-GAN generator only, B=32 x 256 units, full size: rows independent (bit for bit), two rows
+    against the oracle, output finite and inside (-1, 1)."""
+    h = synth.default_voc_config()
+    vsd = synth.synth_voc_state_dict(h, seed=1234, scale=1.0)
+    gen = _gen(h, vsd)
+    b = synth.synth_voc_batch(32, 256, h, seed=0)
+    code, spkr = b["code"].to(DEV), b["spkr"].to(DEV)
+    wav = gen(code=code, spkr=spkr)
+    gen.check_inputs()
+    assert wav.shape == (32, 1, 256 * 320) and bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 1.0
+    assert torch.equal(gen(code=code[7:8].contiguous(), spkr=spkr[7:8].contiguous()), wav[7:8])
+    worst = 0.0
+    for r in (0, 31):
+        with torch.no_grad():
+            ref = O.code_generator_forward(vsd, h, b["code"][r:r + 1], b["spkr"][r:r + 1])
+        worst = max(worst, float((wav[r:r + 1].cpu() - ref).abs().max()))
+    _report(test="config2_voc_b32_rows_vs_oracle", precision=prec, wav_max_abs_err=worst)
+    assert worst <= 5e-5
+
+
+def test_config5_long_form_full_size_chunked_and_whole(tmp_path, prec):
+    """BASELINE configs[4]: B=8 x 1500 units (30 s) on the FULL-SIZE models: chunk-streamed (256-unit chunks, receptive-field
+    halo) equals whole-utterance synthesis, one row equals the oracle, and the full-size TTE at S=375 -> L=1500 gives the
+    oracle's ids (the attention there runs the any-length path, no materialised B*H*T^2 score tensor)."""
+    h = synth.default_voc_config()
+    vsd = synth.synth_voc_state_dict(h, seed=1234, scale=1.0)
+    gen = _gen(h, vsd)
+    b = synth.synth_voc_batch(8, 1500, h, seed=11)
+    code, spkr = b["code"].to(DEV), b["spkr"].to(DEV)
+    whole = gen(code=code, spkr=spkr)
+    chunked = gen.forward_chunked(chunk_units=256, code=code, spkr=spkr)
+    d = float((whole - chunked).abs().max())
+    with torch.no_grad():
+        ref = O.code_generator_forward(vsd, h, b["code"][5:6], b["spkr"][5:6])
+    e_whole, e_chunk = float((whole[5:6].cpu() - ref).abs().max()), float((chunked[5:6].cpu() - ref).abs().max())
+    _report(test="config5_voc_b8_u1500", precision=prec, chunked_vs_whole=d, whole_vs_oracle=e_whole, chunked_vs_oracle=e_chunk)
+    assert d <= (2e-6 if prec == "f32" else 2e-5)
+    assert e_whole <= 5e-5 and e_chunk <= 5e-5
+    cfg = synth.default_tte_config()
+    vocab, n_spk = 300, 10
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=42, forced_duration=4)
+    model = _parrot(cfg, vocab, n_spk, tsd, tmp_path)
+    row = _tte_vs_oracle(model, tsd, cfg, synth.synth_tte_batch(8, 375, vocab, n_spk, seed=3, ragged=True), "B8xS375xL1500", prec)
+    assert row["positions"] > 8 * 700
+
+
+def test_length_regulator_kernel_on_the_adversarial_golden(golden_dir):
+    """tests/golden/tte_blocks.npz lr_*: zero durations, an all-zero row, a single long token -- through
+    length_regulate_kernel itself (parrot_length_regulator), bit-exact incl. the `ids <= len` mask (quirk Q2)."""
+    z = np.load(os.path.join(golden_dir, "tte_blocks.npz"))
+    out, mask, lens = ops.length_regulator(torch.from_numpy(z["lr_seq"]).to(DEV), torch.from_numpy(z["lr_dur"]).to(DEV))
+    assert np.array_equal(out.cpu().numpy(), z["lr_out"])
+    assert np.array_equal(mask.cpu().numpy(), z["lr_mask"])
+    assert lens == z["lr_dur"].sum(1).tolist()
+    # other shapes against the oracle: long rows, D not a tile multiple, a row of zeros in the middle
+    rng = np.random.Generator(np.random.PCG64(5))
+    for B, S, D in [(3, 70, 20), (2, 129, 256), (5, 1, 7)]:
+        seq = torch.from_numpy(rng.standard_normal((B, S, D)).astype(np.float32))
+        dur = torch.from_numpy(rng.integers(0, 6, size=(B, S), dtype=np.int64))
+        if B > 2:
+            dur[1] = 0
+        if int(dur.sum(1).max()) == 0:
+            dur[0, 0] = 3
+        ex, tm, ln = O.length_regulator(seq, dur)
+        out, mask, lens = ops.length_regulator(seq.to(DEV), dur.to(DEV))
+        assert torch.equal(out.cpu(), ex) and torch.equal(mask.cpu(), tm) and lens == ln
+    with pytest.raises(ValueError):
+        ops.length_regulator(torch.zeros(1, 2, 4, device=DEV), torch.zeros(1, 2, dtype=torch.int64, device=DEV))
+
+
+def test_resblock2_at_full_width(prec):
+    """ResBlock2 (utils/vocoder/models.py:47-66) on the full-width generator (512 initial channels), not only the
+    reduced-width golden."""
+    h = synth.default_voc_config()
+    h["resblock"] = "2"
+    h["resblock_dilation_sizes"] = [[1, 3], [1, 3], [1, 3]]
+    vsd = synth.synth_voc_state_dict(h, seed=77, scale=1.0)
+    gen = _gen(h, vsd)
+    b = synth.synth_voc_batch(2, 12, h, seed=2)
+    with torch.no_grad():
+        st_ref = {}
+        ref = O.code_generator_forward(vsd, h, b["code"], b["spkr"], stages=st_ref)
+    st = {}
+    y = gen(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV), stages=st).cpu()
+    for k in ("conv_pre", "mrf0", "mrf2", "mrf4"):
+        assert float((st[k].cpu() - st_ref[k]).abs().max()) <= 3e-5 * max(1.0, float(st_ref[k].abs().max())), k
+    err = float((y - ref).abs().max())
+    _report(test="resblock2_full_width", precision=prec, wav_max_abs_err=err)
+    assert err <= 5e-5
+
+
+NON_DEFAULT_VOC = [
+    dict(upsample_rates=[8, 5, 2, 2], upsample_kernel_sizes=[16, 11, 4, 4], upsample_initial_channel=128),
+    dict(upsample_rates=[4, 4], upsample_kernel_sizes=[8, 8], upsample_initial_channel=64, resblock_kernel_sizes=[3, 5],
+         resblock_dilation_sizes=[[1, 2], [2, 6]]),
+    dict(upsample_rates=[5, 4, 4, 2, 2], upsample_kernel_sizes=[11, 8, 8, 4, 4], upsample_initial_channel=256,
+         resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], multispkr=None, model_in_dim=16),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(NON_DEFAULT_VOC)))
+def test_non_default_vocoder_configs_match_oracle(idx, prec):
+    """Other `upsample_rates` / kernel sizes / MRF shapes than utils/vocoder/config.json (models.py:80-89), against the oracle."""
+    h = synth.small_voc_config()
+    h.update(NON_DEFAULT_VOC[idx])
+    vsd = synth.synth_voc_state_dict(h, seed=50 + idx, scale=1.0)
+    gen = _gen(h, vsd)
+    hop = int(np.prod(h["upsample_rates"]))
+    assert gen.upsample_factor == hop
+    for B, U in [(2, 23), (1, 130)]:
+        b = synth.synth_voc_batch(B, U, h, seed=U)
+        with torch.no_grad():
+            ref = O.code_generator_forward(vsd, h, b["code"], b["spkr"])
+        y = gen(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV)).cpu()
+        assert y.shape == ref.shape == (B, 1, U * hop)
+        assert float((y - ref).abs().max()) <= 5e-5
+
+
+NON_DEFAULT_TTE = [
+    dict(enc_heads=4, dec_heads=1, kernels=[3, 3], d_model=64),      # head dims 16 and 64
+    dict(enc_heads=1, dec_heads=2, kernels=[5, 1], d_model=128),     # head dims 128 (fused core) and 64
+    dict(enc_heads=2, dec_heads=2, kernels=[9, 1], d_model=256),     # the shipped head dim, reduced depth / FFN width
+]
+
+
+@pytest.mark.parametrize("idx", range(len(NON_DEFAULT_TTE)))
+def test_non_default_tte_configs_match_oracle(tmp_path, idx, prec):
+    """Other `n_head` / `conv_kernel_sizes` / `d_model` than utils/TTE/TTE_config.yaml:13-30, against the oracle."""
+    nd = NON_DEFAULT_TTE[idx]
+    cfg = synth.small_tte_config()
+    cfg["transformer"].update(d_model=nd["d_model"], conv_kernel_sizes=nd["kernels"])
+    cfg["transformer"]["encoder"]["n_head"] = nd["enc_heads"]
+    cfg["transformer"]["decoder"]["n_head"] = nd["dec_heads"]
+    cfg["duration_predictor"]["n_filter"] = nd["d_model"]
+    tsd = synth.synth_tte_state_dict(cfg, 40, 3, seed=60 + idx)
+    model = _parrot(cfg, 40, 3, tsd, tmp_path)
+    for B, S in [(3, 21), (2, 90)]:
+        batch = synth.synth_tte_batch(B, S, 40, 3, seed=S, ragged=True)
+        with torch.no_grad():
+            ref = O.tte_forward(tsd, cfg, batch)
+            ref_rows = O.tte_infer(tsd, cfg, batch)
+        gb = {k: v.to(DEV) for k, v in batch.items()}
+        logits, _, tgt_mask, log_dur = model(gb, inference=True)
+        m = ref["tgt_mask"]
+        assert torch.equal(tgt_mask.cpu(), m)
+        assert float((log_dur.cpu() - ref["log_dur"]).abs().max()) <= 2e-5
+        assert float((logits.cpu() - ref["logits"])[m].abs().max()) <= 1e-4
+        top2 = torch.topk(ref["logits"], 2, dim=-1).values
+        if bool((((top2[..., 0] - top2[..., 1]) > 1e-4) | ~m).all()):
+            assert model.infer(gb) == ref_rows
+
+
+@pytest.mark.parametrize("mode,floor_db", [("bf16", 35.9), ("f16", 50.0)])
+def test_reduced_precision_operating_point_snr(golden_dir, mode, floor_db):
+    """BASELINE configs[2] "bf16": operands rounded once to bf16 (or fp16), ONE MFMA per product group, fp32 accumulate, fp32
+    residual stream.  Not a parity mode: reported as SNR against the reference's fp32 waveform; the yardstick is the
+    reference generator itself under torch CPU bf16 autocast, 35.9 dB.  fp16 operands score ~54 dB."""
+    z = np.load(os.path.join(golden_dir, "voc_full_u40.npz"))
+    m = json.loads(str(z["meta"]))
+    h = synth.default_voc_config()
+    sd = synth.synth_voc_state_dict(h, seed=m["seed_w"], scale=m["scale"])
+    ops.set_default_precision(ops.PREC_NAMES[mode])
+    try:
+        g = _gen(h, sd)
+        y = g(code=torch.from_numpy(z["code"]).to(DEV), spkr=torch.from_numpy(z["spkr"]).to(DEV)).cpu().numpy().astype(np.float64)
+    finally:
+        ops.set_default_precision(ops.PREC_DEFAULT)
+    ref = z["wav"].astype(np.float64)
+    snr = 10.0 * np.log10((ref ** 2).sum() / ((y - ref) ** 2).sum())
+    _report(test="reduced_precision_snr", mode=mode, snr_db=float(snr), max_abs_err=float(np.abs(y - ref).max()))
+    assert np.isfinite(y).all() and snr >= floor_db

@@ -1,0 +1,107 @@
+"""GPU, 2 processes on ONE device: the exact N>1 code path of bench.py / SynthesisPipeline that the 8-GPU scaling run
+executes -- one process per rank, batch shard by row, HIP synthesis per shard, one waveform gather to rank 0 --
+exercised on the single MI355X of the test box.  RCCL refuses two ranks on one device, so the collective backend here
+is gloo (PARROT_DIST_BACKEND); everything else (init_from_env, shard_batch, the HIP pipeline, gather_waveforms'
+shape exchange / padding / receive buffer) is the production code.  Counterpart of the reference's Pool(8) fan-out,
+utils/vocoder/inference.py:201-205,255."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _models(tmp):
+    from parrot_tts_amd import synth
+    from parrot_tts_amd.tte import Parrot
+    from parrot_tts_amd.vocoder import AttrDict, CodeGenerator
+    cfg, h = synth.small_tte_config(), synth.small_voc_config()
+    cfg["path"]["root_path"] = tmp
+    os.makedirs(tmp, exist_ok=True)
+    with open(os.path.join(tmp, "speakers.json"), "w") as f:
+        json.dump({"a": 0, "b": 1}, f)
+    vocab, n_spk = 30, 2
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=31)
+    for k in list(tsd):  # the small vocoder knows 100 units: keep the head inside that range
+        if k.endswith("head.weight") or k.endswith("head.bias"):
+            tsd[k] = tsd[k].clone()
+            tsd[k][100:] = -10.0 if k.endswith("bias") else 0.0
+    vsd = synth.synth_voc_state_dict(h, seed=32)
+    parrot = Parrot(cfg, vocab, 0)
+    parrot.load_state_dict(tsd)
+    gen = CodeGenerator(AttrDict(h))
+    gen.load_state_dict(vsd)
+    return parrot.eval(), gen.eval(), vocab, n_spk
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PARROT_DIST_BACKEND="gloo")
+    from parrot_tts_amd import dist as pdist, synth
+    from parrot_tts_amd.pipeline import SynthesisPipeline
+    r, w, local = pdist.init_from_env("nccl")  # the env override turns this into gloo: both ranks share cuda:0
+    dev = pdist.local_device(local)
+    assert dev == torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    parrot, gen, vocab, n_spk = _models(os.path.join(out_dir, f"tte{rank}"))
+    pipe = SynthesisPipeline(parrot.to(dev), gen.to(dev))
+    full = synth.synth_tte_batch(5, 13, vocab, n_spk, seed=7, ragged=True)  # 5 rows over 2 ranks: 3 + 2, ragged lengths
+    mine = {k: v.to(dev) for k, v in pdist.shard_batch(full, r, w).items()}
+    out = pipe(mine)
+    got = pdist.gather_waveforms(out["wav"], dst=0, n_samples=out["n_samples"])
+    rows = pdist.gather_ragged_rows([row[m].tolist() for row, m in zip(out["ids"].cpu(), out["tgt_mask"].cpu())], dst=0)
+    if r == 0:
+        wav_all, n_all = got
+        # single-process runs of the SAME shards (the TTE's results depend on the padded batch, quirk Q7: shard, never re-pad)
+        at = 0
+        for rr in range(w):
+            shard = {k: v.to(dev) for k, v in pdist.shard_batch(full, rr, w).items()}
+            ref = pipe(shard)
+            for b in range(ref["wav"].shape[0]):
+                n = int(ref["n_samples"][b])
+                assert int(n_all[at]) == n
+                assert torch.equal(wav_all[at, :, :n], ref["wav"][b, :, :n]), (rr, b)
+                assert rows[at] == ref["ids"][b][ref["tgt_mask"][b]].tolist()
+                at += 1
+        assert at == 5 and wav_all.shape[0] == 5
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    else:
+        assert got is None and rows is None
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_single_process_shards(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").read_text() == "ok"
+
+
+def test_bench_runs_under_torchrun_with_two_ranks(tmp_path):
+    """bench.py exactly as the driver launches it for N=2 (torch.distributed.run, one process per rank), both ranks on the
+    one visible GPU: rc 0, one JSON line from rank 0 with n_gpus 2 and the whole-job sample count."""
+    env = dict(os.environ, PARROT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--no-cpu-baseline", "--no-alt"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
+    assert abs(res["value"] * res["ms_per_step"] / 1e3 - 8 * 256 * 320) < 1.0  # value = all ranks' samples / max-over-ranks time

@@ -61,14 +61,14 @@ def fused(request):
     ops.set_fused_resblocks(2)
 
 
-@pytest.fixture(params=["f32", "bf16x6"])
+@pytest.fixture(params=["f32", "bf16x6", "f16x3"])
 def prec(request):
-    """Run a model-level test under both product-evaluation modes of the conv kernel (include/parrot_hip.h
-    PARROT_PREC_*): exact fp32 MFMA, and the split-bf16 scheme (fp32 data, 6 bf16 MFMAs per product group).
-    Both are held to the SAME tolerances."""
-    ops.set_default_precision(ops.PREC_BF16X6 if request.param == "bf16x6" else ops.PREC_F32)
+    """Run a model-level test under every parity-grade product-evaluation mode of the conv kernels (include/parrot_hip.h
+    PARROT_PREC_*): exact fp32 MFMA, the split-bf16 scheme (6 bf16 MFMAs per product group) and the split-fp16 scheme
+    (3 fp16 MFMAs; the library default) -- fp32 data and accumulation in all three.  All are held to the SAME tolerances."""
+    ops.set_default_precision(ops.PREC_NAMES[request.param])
     yield request.param
-    ops.set_default_precision(ops.PREC_BF16X6)  # the library default
+    ops.set_default_precision(ops.PREC_DEFAULT)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -126,8 +126,9 @@ def test_conv1d_matches_torch(case, tile):
     assert float((y - y_ref).abs().max()) <= tol
 
 
-@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] >= 64], ids=lambda c: "x".join(map(str, c)))
-def test_conv1d_bf16x6_matches_torch(case):
+@pytest.mark.parametrize("scheme", ["bf16x6", "f16x3"])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] >= 32], ids=lambda c: "x".join(map(str, c)))
+def test_conv1d_split_schemes_match_fp64(case, scheme):
     cin, cout, k, dil, B, T, pre, res, act = case
     rng = _rng(cin * 31 + cout * 17 + k + dil + T)
     w = _randn(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
@@ -142,13 +143,35 @@ def test_conv1d_bf16x6_matches_torch(case):
         y_ref = y_ref + r.double()
     args = dict(dilation=dil, padding=pad, pre_act=int(pre), pre_slope=0.1, act=act)
     xd, rd = x.to(DEV), None if r is None else r.to(DEV)
-    y6 = ops.ConvPlan(w, b, precision=ops.PREC_BF16X6, **args)(xd, rd).cpu().double()
+    y6 = ops.ConvPlan(w, b, precision=ops.PREC_NAMES[scheme], **args)(xd, rd).cpu().double()
     y32 = ops.ConvPlan(w, b, precision=ops.PREC_F32, **args)(xd, rd).cpu().double()
     scale = max(1.0, float(y_ref.abs().max()))
     e6, e32 = float((y6 - y_ref).abs().max()) / scale, float((y32 - y_ref).abs().max()) / scale
-    _report(test="conv_bf16x6_vs_fp64", case="x".join(map(str, case)), err_bf16x6=e6, err_f32_mfma=e32)
+    _report(test="conv_split_vs_fp64", scheme=scheme, case="x".join(map(str, case)), err_split=e6, err_f32_mfma=e32)
     assert e6 <= 2e-5
-    assert e6 <= 4 * e32 + 1e-6, "split-bf16 evaluation must stay in the same error class as the exact fp32 kernel"
+    assert e6 <= 4 * e32 + 1e-6, "a split evaluation must stay in the same error class as the exact fp32 kernel"
+
+
+def test_split_f16_scaling_covers_small_and_large_operands_and_overflows_loudly():
+    """The fp16 split pre-scales activations by 2^3 and the layer's weights by a power of two: full relative accuracy for
+    tiny weights (1e-6 scale) and activations from 1e-3 to 1e3 in one tensor; beyond fp16's range (|x| >= 8190) the
+    result is non-finite -- never a silently wrong finite number."""
+    rng = _rng(77)
+    cin, cout, k, T = 64, 64, 3, 512
+    mag = torch.from_numpy(10.0 ** rng.uniform(-3, 3, size=(1, cin, T))).float()
+    x = _randn(rng, 1, cin, T) * mag
+    for wscale in (1e-6, 1.0, 300.0):
+        w = _randn(rng, cout, cin, k, scale=wscale / np.sqrt(cin * k))
+        y_ref = F.conv1d(x.double(), w.double(), None, padding=1)
+        y = ops.ConvPlan(w, None, padding=1, precision=ops.PREC_F16X3)(x.to(DEV)).cpu().double()
+        y32 = ops.ConvPlan(w, None, padding=1, precision=ops.PREC_F32)(x.to(DEV)).cpu().double()
+        scale = float(y_ref.abs().max())
+        e, e32 = float((y - y_ref).abs().max()) / scale, float((y32 - y_ref).abs().max()) / scale
+        _report(test="f16x3_dynamic_range", wscale=wscale, err_f16x3=e, err_f32_mfma=e32)
+        assert e <= 4 * e32 + 1e-6
+    x[0, 3, 100] = 9000.0
+    y = ops.ConvPlan(w, None, padding=1, precision=ops.PREC_F16X3)(x.to(DEV)).cpu()
+    assert not bool(torch.isfinite(y[0, :, 99:102]).all())
 
 
 def test_conv1d_epilogues_accumulate_like_mrf():
@@ -170,7 +193,7 @@ CONVT_CASES = [(512, 256, 11, 5, 2, 40), (256, 128, 8, 4, 1, 90), (128, 64, 8, 4
                (32, 16, 4, 2, 2, 513), (8, 4, 5, 2, 1, 19), (8, 4, 3, 3, 1, 10), (6, 6, 7, 2, 2, 1)]
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_transpose1d_matches_torch(case, precision):
     cin, cout, k, u, B, T = case

@@ -122,6 +122,34 @@ def test_generator_state_dict_layouts(tmp_path):
     assert CodeGenerator(AttrDict(dict(h, f0=True))).f0 is True  # stored and, like the reference's forward, never used
 
 
+def test_weight_reload_through_a_wrapper_invalidates_the_cached_handle(tmp_path):
+    """torch's load_state_dict never calls a CHILD module's load_state_dict override, so the packed-weight handle must be
+    invalidated from hooks torch always runs + a parameter-version fingerprint: reload through LitParrot /
+    nn.Sequential, in-place parameter writes and .to() all change what the next forward must pack."""
+    from parrot_tts_amd.ops import param_fingerprint
+    d, cfg = _tte_dir(tmp_path)
+    lit = checkpoint.LitParrot(cfg, 30, 0)
+    calls = []
+    lit.parrot._invalidate = lambda: calls.append("tte")
+    fp0 = param_fingerprint(lit.parrot)
+    lit.load_state_dict({"parrot." + k: v for k, v in synth.synth_tte_state_dict(cfg, 30, 2, seed=9).items()})
+    assert calls == ["tte"] and param_fingerprint(lit.parrot) != fp0
+    fp1 = param_fingerprint(lit.parrot)
+    with torch.no_grad():
+        lit.parrot.state_dict()["head.bias"].add_(1.0)  # in-place edit of one parameter
+    assert param_fingerprint(lit.parrot) != fp1
+    h = synth.small_voc_config()
+    g = CodeGenerator(AttrDict(h))
+    seq = torch.nn.Sequential(g)
+    g._invalidate = lambda: calls.append("voc")
+    fp0 = param_fingerprint(g)
+    seq.load_state_dict({"0." + k: v for k, v in synth.synth_voc_state_dict(h, seed=4).items()})
+    assert calls[-1] == "voc" and param_fingerprint(g) != fp0
+    fp1 = param_fingerprint(g)
+    g.conv_pre.remove_weight_norm()  # parameter objects replaced
+    assert param_fingerprint(g) != fp1
+
+
 def test_no_cpu_fallback_and_oracle_is_not_imported_by_the_product(tmp_path):
     d, cfg = _tte_dir(tmp_path)
     m = Parrot(cfg, 30, 0).eval()
@@ -172,12 +200,13 @@ def test_profile_kernel_names_fold_to_bench_rows():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     import bench
-    cases = {"conv_bf16x6_kernel<2, 2, 2, 2, 2, 11, 1>": "conv_bf16x6_kernel<2,2,2,2,2>",
-             "conv_bf16x6_kernel<2, 2, 2, 1, 3, 1, 4>": "conv_bf16x6_kernel<2,2,2,1,3>",
-             "conv_bf16x6_kernel<1, 4, 1, 4, 2, 3, 1>": "conv_bf16x6_kernel<1,4,1,4,2>",
-             "resblock_bf16x6_kernel<4>": "resblock_bf16x6_kernel", "resblock16_bf16x6_kernel": "resblock16_bf16x6_kernel",
+    cases = {"conv_split_kernel<parrot::SchF16x3, 2, 2, 2, 2, 2, 11, 1>": "conv_split_kernel<SchF16x3,2,2,2,2,2>",
+             "conv_split_kernel<parrot::SchF16x3, 2, 2, 2, 1, 3, 1, 4>": "conv_split_kernel<SchF16x3,2,2,2,1,3>",
+             "conv_split_kernel<parrot::SchF16x3, 1, 4, 1, 4, 2, 3, 1>": "conv_split_kernel<SchF16x3,1,4,1,4,2>",
+             "resblock_split_kernel<parrot::SchF16x3, 4>": "resblock_split_kernel<SchF16x3>",
+             "resblock16_split_kernel<parrot::SchF16x3>": "resblock16_split_kernel<SchF16x3>",
              "conv1_valu_kernel<7>": "conv1_valu_kernel", "conv1_valu7_vec_kernel": "conv1_valu_kernel", "convt_valu_kernel<16, 4, 2, 1>": "convt_valu_kernel<16,4,2,1>",
              "conv_mfma_kernel<2, 2, 2, 2, 16, 3>": "conv_mfma_kernel<2,2,2,2,16,3>"}
     for raw, want in cases.items():
         assert mod.norm(raw) == want
-        assert want in bench.TILE_NAMES
+        assert want in bench.tile_names("f16x3")

@@ -15,13 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def norm(name: str) -> str:
-    name = name.replace(" ", "")
-    m = re.match(r"(conv_bf16x6_kernel<\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
+    name = name.replace(" ", "").replace("parrot::", "")
+    m = re.match(r"(conv_split_kernel<Sch\w+,\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
     if m:
         return m.group(1) + ">"
     if name == "conv1_valu7_vec_kernel":
         return "conv1_valu_kernel"
-    return re.sub(r"^(resblock_bf16x6_kernel|conv1_valu_kernel)<\d+>$", r"\1", name)  # instantiations that share one bench.py row
+    name = re.sub(r"^resblock_split_kernel<(Sch\w+),\d+>$", r"resblock_split_kernel<\1>", name)
+    return re.sub(r"^(conv1_valu_kernel)<\d+>$", r"\1", name)  # instantiations that share one bench.py row
 
 
 def load(path: str, col: str):
