@@ -210,7 +210,7 @@ def voc_layer_shapes(h: dict):
     for i in range(len(h["upsample_rates"])):
         ch = c0 // (2 ** (i + 1))
         for j, k in enumerate(h["resblock_kernel_sizes"]):
-            n_conv = 3 if str(h["resblock"]) == "1" else 2
+            n_conv = len(h["resblock_dilation_sizes"][j])  # (3 for the shipped ResBlock1 config, 2 for the ResBlock2 goldens)
             for m in range(n_conv):
                 if str(h["resblock"]) == "1":
                     out.append((f"resblocks.{i * nk + j}.convs1.{m}", "conv", ch, ch, k, 1))

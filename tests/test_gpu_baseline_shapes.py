@@ -220,7 +220,7 @@ def test_non_default_tte_configs_match_oracle(tmp_path, idx, prec):
     """Other `n_head` / `conv_kernel_sizes` / `d_model` than utils/TTE/TTE_config.yaml:13-30, against the oracle."""
     nd = NON_DEFAULT_TTE[idx]
     cfg = synth.small_tte_config()
-    cfg["transformer"].update(d_model=nd["d_model"], conv_kernel_sizes=nd["kernels"])
+    cfg["transformer"].update(d_model=nd["d_model"], conv_kernel_sizes=nd["kernels"], max_len=1200)
     cfg["transformer"]["encoder"]["n_head"] = nd["enc_heads"]
     cfg["transformer"]["decoder"]["n_head"] = nd["dec_heads"]
     cfg["duration_predictor"]["n_filter"] = nd["d_model"]
