@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_mfma.h"
+#include "conv_split.h"
 #include "kernels_misc.h"
 
 namespace parrot {
@@ -199,6 +200,259 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
             for (int m = 0; m < MT; ++m)
                 if (tq0 + m * 32 + l31 < T) ctx[row + tq0 + m * 32 + l31] = acc[m][r];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flash-style attention core for ANY sequence length on the fp16 split pipe (SchF16x3: 3 fp16 MFMAs per product group,
+// fp32 accumulate -- conv_split.h): softmax(q k^T * hd^-1/2 + key mask) v of the torch MHA math path (fft.py:56)
+// without ever materialising a (T, T) score tensor.  One workgroup = 128 queries of one (batch, head); wave w owns
+// queries [32w, 32w+32) and walks the keys in tiles of 32 with an online softmax:
+//
+//   S^T[key][query] = sum_c K[c][key] (alpha q[c][query])       A = K tile (LDS, [key][channel] fp16 pieces), B = Q (registers)
+//   m, l, O updated per tile:  m' = max(m, max_key S);  O *= e^(m-m');  l = l e^(m-m') + sum_key e^(S-m')
+//   O[c][query] += sum_key V[c][key] P[query][key]              A = V tile (LDS, [channel][key] fp16 pieces), B = P (registers)
+//
+// With queries on the MFMA column axis a lane owns ONE query: its 16 accumulator registers of S^T are 16 keys of that
+// query (the other 16 sit in lane ^ 32), so the softmax statistics are per-lane scalars, and the probabilities feed the
+// second GEMM straight from registers -- the C/D layout of S^T is the B-operand layout of P up to a fixed permutation of
+// the keys inside a k-step, which the V fragments are read with as well.  K / V tiles are staged (global -> fp16 pieces
+// -> LDS) once per workgroup and shared by its four waves, double buffered, one barrier per tile.
+// Scales (powers of two): q, k, v pieces carry 2^3, P pieces 2^11; undone on the scores / in the final normalisation.
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_flash_kernel(const AttnParams p) {
+    using SCH = SchF16x3;
+    constexpr int KS = HD / 16;            // k-steps over the head channels (scores)
+    constexpr int MT = (HD + 31) / 32;     // 32-channel tiles of the context
+    constexpr int KT = 32;                 // keys per tile
+    constexpr int KROW = HD * 2 + 16;      // bytes per key row of a K piece (+16: conflict-free ds_read_b128 across keys)
+    constexpr int VROW = KT * 2 + 8;       // bytes per channel row of a V piece
+    constexpr int KBYTES = KT * KROW, VBYTES = MT * 32 * VROW;
+    constexpr int BUF = 2 * (KBYTES + VBYTES);  // [K p0][K p1][V p0][V p1]
+    constexpr float PS = 2048.f;           // scale of the probability pieces
+    static_assert(HD % 16 == 0 && HD <= 128, "head dim: multiple of 16, <= 128");
+    extern __shared__ __attribute__((aligned(16))) char fsm[];  // [2][BUF]
+
+    const int T = p.T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
+    const int tq = blockIdx.x * 128 + wave * 32 + l31;  // this lane's query
+    const long DT = (long)p.D * T;
+    const float* __restrict__ q = p.qkv + (long)b * 3 * DT + (long)h * HD * T;
+    const float* __restrict__ k = q + DT;
+    const float* __restrict__ v = q + 2 * DT;
+    const uint8_t* __restrict__ kv = p.valid + (long)b * T;
+
+    // ---- Q fragments (B operand: lane = query, 8 channels 16 ks + 8 half ..): registers for the whole kernel --------
+    s16x8 Q[KS][2];
+    {
+        const float* __restrict__ qp = q + min(tq, T - 1);
+        const float qs = p.alpha * SCH::XS;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            unsigned w[4][2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 16 * ks + 8 * half + 2 * e;
+                SCH::split(qp[(long)c * T] * qs, qp[(long)(c + 1) * T] * qs, w[e]);
+            }
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) Q[ks][pc] = __builtin_bit_cast(s16x8, uint4{w[0][pc], w[1][pc], w[2][pc], w[3][pc]});
+        }
+    }
+
+    // ---- K / V tile staging ---------------------------------------------------------------------------------------
+    // K: thread (t = tid & 31, channel pair tid >> 5 + 8 i): two coalesced row loads -> packed fp16 pair at [t][c, c+1]
+    // V: thread (key pair tid & 15, channel tid >> 4 + 16 i): two loads -> packed pair at [c][t, t+1]
+    constexpr int KI = HD / 16, VI = MT * 2;
+    float kraw[KI][2], vraw[VI][2];
+    auto load_k = [&](int t0) __attribute__((always_inline)) {
+        const int t = t0 + (tid & 31);
+        const bool ok = t < T;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int c = 2 * ((tid >> 5) + 8 * i);
+            kraw[i][0] = ok ? k[(long)c * T + t] : 0.f;
+            kraw[i][1] = ok ? k[(long)(c + 1) * T + t] : 0.f;
+        }
+    };
+    auto store_k = [&](char* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int c = 2 * ((tid >> 5) + 8 * i);
+            unsigned w[2];
+            SCH::split(kraw[i][0] * SCH::XS, kraw[i][1] * SCH::XS, w);
+            char* dst = buf + (tid & 31) * KROW + c * 2;
+            *reinterpret_cast<unsigned*>(dst) = w[0];
+            *reinterpret_cast<unsigned*>(dst + KBYTES) = w[1];
+        }
+    };
+    auto load_v = [&](int t0) __attribute__((always_inline)) {
+        const int t = t0 + 2 * (tid & 15);
+#pragma unroll
+        for (int i = 0; i < VI; ++i) {
+            const int c = (tid >> 4) + 16 * i;
+            const bool cok = c < HD;
+            vraw[i][0] = (cok && t < T) ? v[(long)c * T + t] : 0.f;
+            vraw[i][1] = (cok && t + 1 < T) ? v[(long)c * T + t + 1] : 0.f;
+        }
+    };
+    auto store_v = [&](char* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < VI; ++i) {
+            const int c = (tid >> 4) + 16 * i;
+            unsigned w[2];
+            SCH::split(vraw[i][0] * SCH::XS, vraw[i][1] * SCH::XS, w);
+            char* dst = buf + 2 * KBYTES + c * VROW + (tid & 15) * 4;
+            *reinterpret_cast<unsigned*>(dst) = w[0];
+            *reinterpret_cast<unsigned*>(dst + VBYTES) = w[1];
+        }
+    };
+
+    f32x16 O[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[mt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    load_k(0);
+    load_v(0);
+    store_k(fsm);
+    store_v(fsm);
+    __syncthreads();
+
+    const int ntile = (T + KT - 1) / KT;
+    for (int kt = 0; kt < ntile; ++kt) {
+        const char* __restrict__ cur = fsm + (kt & 1) * BUF;
+        char* nxt = fsm + ((kt + 1) & 1) * BUF;
+        const int t0 = kt * KT;
+        const bool more = kt + 1 < ntile;
+        // key validity of this tile as a wave-uniform bit mask (key padding mask of the batch row; keys past T)
+        const unsigned long long vb = __ballot((lane < KT) && (t0 + lane < T) && kv[min(t0 + lane, T - 1)] != 0);
+        const unsigned vmask = (unsigned)vb;
+        if (more) load_k(t0 + KT);
+        // ---- scores: S^T = K^T-tile x Q ---------------------------------------------------------------------------
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        {   // K fragments one k-step ahead (explicit double buffer; the sched_barrier keeps hipcc from hoisting all KS fetches)
+            const char* src = cur + l31 * KROW + 8 * half * 2;
+            s16x8 kf[2][2];
+            kf[0][0] = *reinterpret_cast<const s16x8*>(src);
+            kf[0][1] = *reinterpret_cast<const s16x8*>(src + KBYTES);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+                    kf[(ks + 1) & 1][0] = *reinterpret_cast<const s16x8*>(src + (ks + 1) * 32);
+                    kf[(ks + 1) & 1][1] = *reinterpret_cast<const s16x8*>(src + (ks + 1) * 32 + KBYTES);
+                }
+                S = mfma32<SCH>(kf[ks & 1][1], Q[ks][0], S);
+                S = mfma32<SCH>(kf[ks & 1][0], Q[ks][1], S);
+                S = mfma32<SCH>(kf[ks & 1][0], Q[ks][0], S);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) {
+            store_k(nxt);
+            load_v(t0 + KT);
+        }
+        // ---- online softmax (per lane = per query; the two half-waves hold complementary keys) ----------------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+            S[r] = ((vmask >> key) & 1u) ? S[r] * (1.f / (SCH::XS * SCH::XS)) : -INFINITY;
+            mx = fmaxf(mx, S[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;  // (no valid key yet: every exp below is e^-inf = 0)
+        const float resc = expf(m_run - m_safe);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[r] = expf(S[r] - m_safe);  // (in place: S now holds the unnormalised probabilities)
+            ps += S[r];
+        }
+        ps += __shfl_xor(ps, 32);
+        l_run = l_run * resc + ps;
+        m_run = m_new;
+        if (__any(resc != 1.f)) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[mt][r] *= resc;
+        }
+        // probabilities -> B fragments of the second GEMM: k-step s holds registers 8s..8s+7, i.e. the keys
+        // 16 s + 8 (e >> 2) + 4 half + (e & 3): the V fragments below are read in the same order
+        s16x8 P[2][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            unsigned w[4][2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) SCH::split(S[8 * s2 + 2 * e] * PS, S[8 * s2 + 2 * e + 1] * PS, w[e]);
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) P[s2][pc] = __builtin_bit_cast(s16x8, uint4{w[0][pc], w[1][pc], w[2][pc], w[3][pc]});
+        }
+        // ---- context: O += V-tile x P ------------------------------------------------------------------------------
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* src = cur + 2 * KBYTES + (mt * 32 + l31) * VROW + (16 * s2 + 4 * half) * 2;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(src), a1 = *reinterpret_cast<const uint2*>(src + 16);
+                const uint2 c0 = *reinterpret_cast<const uint2*>(src + VBYTES), c1 = *reinterpret_cast<const uint2*>(src + VBYTES + 16);
+                const s16x8 v0 = __builtin_bit_cast(s16x8, uint4{a0.x, a0.y, a1.x, a1.y});
+                const s16x8 v1 = __builtin_bit_cast(s16x8, uint4{c0.x, c0.y, c1.x, c1.y});
+                O[mt] = mfma32<SCH>(v1, P[s2][0], O[mt]);
+                O[mt] = mfma32<SCH>(v0, P[s2][1], O[mt]);
+                O[mt] = mfma32<SCH>(v0, P[s2][0], O[mt]);
+            }
+            if (mt & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) store_v(nxt);
+        __syncthreads();
+    }
+
+    // ---- ctx[h*HD + c][tq] = O / (l * scales): lanes run along the queries -> 128-byte row segments --------------------
+    if (tq < T) {
+        const float inv = 1.f / (l_run * (PS * SCH::XS));
+        float* __restrict__ ctx = p.ctx + (long)b * DT + (long)h * HD * T + tq;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c < HD) ctx[(long)c * T] = O[mt][r] * inv;
+            }
+    }
+}
+
+inline bool attn_flash_has(int hd) { return hd == 128 || hd == 64 || hd == 32 || hd == 16; }
+template <int HD>
+inline hipError_t launch_attn_flash_t(const AttnParams& p, int B, hipStream_t s) {
+    constexpr int MT = (HD + 31) / 32;
+    const size_t lds = (size_t)2 * 2 * (32 * (HD * 2 + 16) + MT * 32 * (32 * 2 + 8));
+    auto kern = attn_flash_kernel<HD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((p.T + 127) / 128, B * p.H), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+inline hipError_t launch_attn_flash(const AttnParams& p, int B, hipStream_t s) {
+    switch (p.hd) {
+        case 128: return launch_attn_flash_t<128>(p, B, s);
+        case 64: return launch_attn_flash_t<64>(p, B, s);
+        case 32: return launch_attn_flash_t<32>(p, B, s);
+        case 16: return launch_attn_flash_t<16>(p, B, s);
+        default: return hipErrorInvalidValue;
     }
 }
 

@@ -65,6 +65,9 @@ struct ConvParams {
     int u_inv16;         // ceil(65536 / u)
     const int32_t* row_len;  // optional per-batch-row true length (in base units); input positions >= row_len[b]*row_len_mul
     int row_len_mul;         // read as zero: each row then sees its OWN sequence edge (ragged batches); null = Tin for all
+    int fold_res;            // 1: the residual tile initialises the accumulator (prologue latency hiding); 0: added once in the
+                             // epilogue -- what the reference computes (conv, THEN + res): when |res| >> |conv sum| (the TTE's residual
+                             // stream) folding makes every accumulation step round at ulp(|res|) instead of ulp(|sum|)
     float acc_scale;         // split schemes with pre-scaled operands (conv_split.h): the accumulator holds acc_scale * sum
     float out_scale;         // = 1 / acc_scale (both exact powers of two; 1 for every other kernel)
 };
@@ -90,7 +93,7 @@ __device__ __forceinline__ void conv_acc_init(const ConvParams& p, f32x16 (&acc)
     float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
     const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
     const bool plain = p.u == 1;
-    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
+    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE && p.fold_res != 0;
     // pass 1: every residual element goes straight into its own accumulator register, so all WM*WN*16 loads are
     // in flight together (clamped addresses; masked lanes are never stored); pass 2 adds the bias.
 #pragma unroll
@@ -136,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
     const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
     const bool plain = p.u == 1;
-    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE;
+    const bool fold_res = plain && rb != nullptr && p.act == ACT_NONE && p.fold_res != 0;
     if (p.out_scale != 1.f) {
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)

@@ -168,11 +168,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
-    const int b = blockIdx.x / p.tiles_n;
-    const int tn = blockIdx.x - b * p.tiles_n;
+    // XCD-aware block order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the M-blocks that read the
+    // SAME input slab are placed 8 ids apart -- same XCD, dispatched back to back: the second one finds the slab in L2
+    // instead of fetching it from HBM again.  id = ((tile / 8) * n_mblocks + mblock) * 8 + tile % 8.
+    const int n_mb = (p.M + BM - 1) / BM;
+    const int grp8 = blockIdx.x / (8 * n_mb), within = blockIdx.x - grp8 * (8 * n_mb);
+    const int mblock = within >> 3;
+    const int tile_id = grp8 * 8 + (within & 7);
+    if (tile_id >= p.tiles_n * p.B) return;  // (grid padded up to a multiple of 8 tiles)
+    const int b = tile_id / p.tiles_n;
+    const int tn = tile_id - b * p.tiles_n;
     const int t0 = tn * BN;
     const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;  // this row's true input length
-    const int grp = (p.groups > 1) ? (blockIdx.y * BM) / p.Mg : 0;
+    const int W = BN + (p.k - 1) * p.dil;  // columns of the slab this layer can reach
+    const int grp = (p.groups > 1) ? (mblock * BM) / p.Mg : 0;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride + (size_t)grp * p.Cin * p.Tin;
 
     // Slab fetch: one buffer descriptor over this batch row's (group's) input.  The per-lane offset is the time index
@@ -194,7 +203,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
         const int so = item / COLS;  // sub-slab * 2 + channel octet (wave-uniform)
         const int col = item - so * COLS;
         const int tin = t0 - p.pad_left + col;
-        voff[i] = (item < LIVE && tin >= 0 && tin < Tlim) ? tin * 4 : (int)0x80000000;  // (idle slots read out of range too)
+        // (idle slots and halo columns beyond the layer's own reach (k-1)*dil read out of range too: zeros, no traffic)
+        voff[i] = (item < LIVE && col < W && tin >= 0 && tin < Tlim) ? tin * 4 : (int)0x80000000;
         soct[i] = __builtin_amdgcn_readfirstlane(min(so, 2 * SUBS - 1) * 8) * row_bytes;
     });
     float stage[ITEMS][8];
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
     };
 
     f32x16 acc[WM][WN];
-    const int m_wave = blockIdx.y * BM + wm * WM * 32;
+    const int m_wave = mblock * BM + wm * WM * 32;
     const int n_wave = t0 + wn * WN * 32;
     conv_acc_init<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
     int abase[WM];  // byte offset of each m-tile's stream (host guarantees the packed stream is < 2 GiB)
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
-        abase[mt] = __builtin_amdgcn_readfirstlane((int)((blockIdx.y * (BM / 32) + wm * WM + mt) * p.n_it * STEP_BYTES));
+        abase[mt] = __builtin_amdgcn_readfirstlane((int)((mblock * (BM / 32) + wm * WM + mt) * p.n_it * STEP_BYTES));
     const unsigned lane16 = lane * 16;
     const int nsup = p.nchunks / SUBS;  // chunks of 16 * SUBS channels (the host only picks SUBS > 1 when this divides)
     const int colbase = wn * WN * 32 + l31;  // this lane's column at tap 0 (tile nt adds 32*nt: same swizzle bit)
@@ -451,12 +461,16 @@ inline void split_tile(int variant, int& bm, int& bn) {
     bm = (variant & 1) ? 64 : 128;
     bn = (variant & 1) ? 256 : 128;
 }
+inline unsigned split_grid(const ConvParams& p, int bm) {  // 1-D: (tiles rounded up to 8) x M-blocks, see the kernel's block order
+    const unsigned tiles = (unsigned)p.tiles_n * p.B, n_mb = (p.M + bm - 1) / bm;
+    return (tiles + 7) / 8 * 8 * n_mb;
+}
 // the (tile, tap count) pairs of the synthesis path get the straight-line kernel, anything else the generic one
 template <class SCH>
 inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStream_t s) {
     int bm, bn;
     split_tile(variant, bm, bn);
-    dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
+    dim3 grid(split_grid(p, bm));
     if (variant == 3) return p.k == 3 ? launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 3>(p, grid, s) : launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 0>(p, grid, s);
     if (variant == 2) {
         if (p.k == 1 && p.nchunks % 4 == 0) return launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4>(p, grid, s);  // 64 channels per barrier
@@ -488,7 +502,7 @@ template <class SCH>
 inline hipError_t launch_conv_split_generic(int variant, const ConvParams& p, hipStream_t s) {
     int bm, bn;
     split_tile(variant, bm, bn);
-    dim3 grid(p.tiles_n * p.B, (p.M + bm - 1) / bm);
+    dim3 grid(split_grid(p, bm));
     if (variant == 3) return launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 0>(p, grid, s);
     if (variant == 2) {
         if (p.k == 1 && p.nchunks % 4 == 0) return launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4>(p, grid, s);

@@ -153,6 +153,7 @@ struct parrot_conv {
     uint16_t* wfrag16 = nullptr;  // [m_tile][chunk*tap][piece][lane][8 x 16 bit]
     int n_it16 = 0;
     float wscale = 1.f;        // power-of-two weight scale inside the fp16 pieces (1 for bf16 schemes)
+    bool late_res = false;     // add the residual in the epilogue instead of folding it into the accumulator init (TTE layers)
     int valu_kind = 0;         // 1: conv1_valu_kernel<7>, 2: convt_valu_kernel<16,4,2,1> (conv_valu.h); weights in their original layout
     float* wraw = nullptr;
 
@@ -465,6 +466,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.groups = c->groups; p.Mg = c->Mg;
     p.row_len = row_len; p.row_len_mul = row_len_mul;
     p.acc_scale = p.out_scale = 1.f;
+    p.fold_res = c->late_res ? 0 : 1;
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
     p.res_bstride = res_bstride > 0 ? res_bstride : p.y_bstride;
@@ -558,7 +560,19 @@ struct parrot_voc {
     int up_total = 1;
     int scheme = 0;                    // PARROT_PREC_* captured at create (immutable afterwards)
     int fused = 2;                     // fused-ResBlock mode captured at create
+    // MRF branch concurrency: the n_kernels ResBlocks of a stage are independent chains until the final sum, so each runs
+    // on its own HIP stream (the caller's + side streams owned by the handle), forked / joined with events; the final
+    // accumulating launches are ordered with events (sum order j = 0, 1, 2 as models.py:100-106).  One branch's
+    // launch tails, prologues and epilogues then overlap another branch's main loops.
+    int mrf_streams = 1;
+    hipStream_t side[PARROT_MAX_KERNELS] = {};
+    hipEvent_t ev_fork = nullptr, ev_last[PARROT_MAX_KERNELS] = {};
     ~parrot_voc() {
+        for (hipStream_t q : side)
+            if (q) (void)hipStreamDestroy(q);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (hipEvent_t e : ev_last)
+            if (e) (void)hipEventDestroy(e);
         for (uint16_t* q : rb_stream)
             if (q) (void)hipFree(q);
         if (dict) (void)hipFree(dict);
@@ -600,6 +614,16 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     v->cfg = *cfg;
     v->scheme = default_prec();
     v->fused = fused_mode();
+    {
+        const char* e = getenv("PARROT_MRF_STREAMS");
+        const bool on = e ? atoi(e) > 1 : true;
+        v->mrf_streams = (on && cfg->n_kernels > 1) ? cfg->n_kernels : 1;
+        if (v->mrf_streams > 1) {
+            for (int j = 1; j < v->mrf_streams; ++j) HIP_TRY(hipStreamCreateWithFlags(&v->side[j], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+            for (int j = 0; j < v->mrf_streams; ++j) HIP_TRY(hipEventCreateWithFlags(&v->ev_last[j], hipEventDisableTiming));
+        }
+    }
     // every upsampling stage must yield exactly T*u samples (k - u even: true for all HiFi-GAN configs): the workspace,
     // the waveform buffer and the ragged-row bookkeeping are sized on that (the reference would return T*u + 1 otherwise)
     for (int i = 0; i < cfg->n_stages; ++i) {
@@ -739,7 +763,7 @@ static bool resblock_fusable(const parrot_voc* v, int stage, int j) {
     return resblock_window(C) - 2 * H >= 128;
 }
 static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, int B, int T, int epi, float div,
-                                 hipStream_t s, const int32_t* row_len, int row_len_mul) {
+                                 hipStream_t s, const int32_t* row_len, int row_len_mul, hipEvent_t before_last = nullptr) {
     const parrot_voc_cfg& c = v->cfg;
     const int per_rb = (c.resblock_type == 1 ? 2 : 1) * c.n_dil;
     const int base = (stage * c.n_kernels + j) * per_rb;
@@ -761,6 +785,7 @@ static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const fl
     p.TT = resblock_window(p.C) - 2 * H;
     p.tiles = (T + p.TT - 1) / p.TT;
     ProfRec rec{};
+    if (before_last) HIP_TRY(hipStreamWaitEvent(s, before_last, 0));
     if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 2, 2.0 * macs, 4.0 * B * (double)p.C * T * (2 + (epi != EPI_STORE ? 1 : 0)), s));
     HIP_TRY(launch_resblock_fused(p, s));
     if (g_prof_on) TRY(prof_close(rec, s));
@@ -775,7 +800,7 @@ static int rbs_hmax() {
     return h;
 }
 static int resblock_split_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, float* tmp_a, float* tmp_b, int B, int T,
-                                 int epi, float div, hipStream_t s, const int32_t* row_len, int row_len_mul) {
+                                 int epi, float div, hipStream_t s, const int32_t* row_len, int row_len_mul, hipEvent_t before_last = nullptr) {
     const parrot_voc_cfg& c = v->cfg;
     const int per_rb = 2 * c.n_dil, k = c.resblock_kernel_sizes[j], C = v->chan(stage);
     const int base = (stage * c.n_kernels + j) * per_rb;
@@ -812,6 +837,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         p.row_len = row_len; p.row_len_mul = row_len_mul;
         ProfRec rec{};
         const double macs = (double)B * C * C * k * T * (m1 - m0);
+        if (last && before_last) HIP_TRY(hipStreamWaitEvent(s, before_last, 0));  // the MRF sum is accumulated in branch order
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
         HIP_TRY(launch_resblock_split(v->scheme, C, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
@@ -827,7 +853,7 @@ extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, i
     Arena a(nullptr, 0);
     a.take<float>((size_t)B * v->cfg.model_in_dim * U);
     const size_t mx = voc_max_act(v, B, U);
-    for (int i = 0; i < 5; ++i) a.take<float>(mx);
+    for (int i = 0; i < 3 + 3 * v->mrf_streams; ++i) a.take<float>(mx);  // stage in / ups out / MRF sum + (T1, RA, RB) per concurrent branch
     return align_up(a.off, 256);
 }
 
@@ -852,8 +878,12 @@ extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, co
     Arena a(ws, ws_bytes);
     float* x0 = a.take<float>((size_t)B * c.model_in_dim * U);
     const size_t mx = voc_max_act(v, B, U);
-    float* P[5];
-    for (int i = 0; i < 5; ++i) P[i] = a.take<float>(mx);
+    const int ns = v->mrf_streams;
+    float* P[3];
+    for (int i = 0; i < 3; ++i) P[i] = a.take<float>(mx);
+    float* TMP[PARROT_MAX_KERNELS][3];  // (T1, RA, RB) per concurrent branch
+    for (int j = 0; j < ns; ++j)
+        for (int q = 0; q < 3; ++q) TMP[j][q] = a.take<float>(mx);
     if (!a.ok) return fail(PARROT_E_NOMEM, "voc_forward: workspace too small");
 
     {
@@ -882,43 +912,53 @@ extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, co
     const int per_rb = (c.resblock_type == 1 ? 2 : 1) * nd;
     for (int i = 0; i < c.n_stages; ++i) {
         float* A = P[ia];
-        float* X = P[(ia + 1) % 5];
-        float* XS = P[(ia + 2) % 5];
-        float* T1 = P[(ia + 3) % 5];
-        float* RA = P[(ia + 4) % 5];
-        float* RB = A;  // the stage input is dead once ups[i] has consumed it
+        float* X = P[(ia + 1) % 3];
+        float* XS = P[(ia + 2) % 3];
         TRY(conv_launch(v->ups[i].get(), A, nullptr, X, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
         T = v->ups[i]->out_len(T);
         mul *= c.upsample_rates[i];
         const size_t n_act = (size_t)B * v->chan(i) * T;
         TRY(snap(1 + 2 * i, X, n_act));
+        if (ns > 1) {  // fork: the side streams see the upsampled stage input
+            HIP_TRY(hipEventRecord(v->ev_fork, s));
+            for (int j = 1; j < ns; ++j) HIP_TRY(hipStreamWaitEvent(v->side[j], v->ev_fork, 0));
+        }
         for (int j = 0; j < nk; ++j) {
+            // the longest branch (largest kernel size = last) stays on the caller's stream
+            const int slot = (ns > 1) ? (j + 1) % nk : 0;
+            hipStream_t sj = (slot == 0) ? s : v->side[slot];
+            float* T1 = TMP[slot][0];
+            float* RA = TMP[slot][1];
+            float* RB = TMP[slot][2];
+            hipEvent_t order = (ns > 1 && j > 0) ? v->ev_last[j - 1] : nullptr;  // XS accumulates in branch order (models.py:100-106)
             const float* r = X;
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
             // (the fused kernels address a batch row with 32-bit byte offsets: rows of 2 GiB and more go layer by layer)
             if (v->fused != 0 && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
-                TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, s, unit_lens, mul));
-                continue;
-            }
-            if (resblock_fusable(v, i, j)) {
-                TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, s, unit_lens, mul));
-                continue;
-            }
-            for (int m = 0; m < nd; ++m) {
-                const bool last = (m == nd - 1);
-                float* dst = last ? XS : ((m & 1) ? RB : RA);
-                if (c.resblock_type == 1) {
-                    TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
-                    TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, s, unit_lens, mul));
-                } else {
-                    TRY(conv_launch(v->rb[base + m].get(), r, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, s, unit_lens, mul));
+                TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, sj, unit_lens, mul, order));
+            } else if (resblock_fusable(v, i, j)) {
+                TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, sj, unit_lens, mul, order));
+            } else {
+                for (int m = 0; m < nd; ++m) {
+                    const bool last = (m == nd - 1);
+                    float* dst = last ? XS : ((m & 1) ? RB : RA);
+                    if (c.resblock_type == 1)
+                        TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, sj, unit_lens, mul));
+                    if (last && order) HIP_TRY(hipStreamWaitEvent(sj, order, 0));
+                    if (c.resblock_type == 1)
+                        TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul));
+                    else
+                        TRY(conv_launch(v->rb[base + m].get(), r, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul));
+                    r = dst;
                 }
-                r = dst;
             }
+            if (ns > 1) HIP_TRY(hipEventRecord(v->ev_last[j], sj));
         }
+        if (ns > 1)  // join: every branch (and with it every reader of X and of the branch temporaries) is done
+            for (int j = 0; j < nk; ++j) HIP_TRY(hipStreamWaitEvent(s, v->ev_last[j], 0));
         TRY(snap(2 + 2 * i, XS, n_act));
-        ia = (ia + 2) % 5;
+        ia = (ia + 2) % 3;
     }
     TRY(conv_launch(v->conv_post.get(), P[ia], nullptr, wav_out, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
     return PARROT_OK;
@@ -954,6 +994,8 @@ struct parrot_tte {
     std::unique_ptr<parrot_conv> dp0, dp1, dp_proj, head;
     std::vector<std::unique_ptr<FftLayer>> enc, dec;
     std::vector<float*> dbg_enc, dbg_dec;  // parrot_tte_debug_stages (tests only)
+    int scheme = 0;                        // PARROT_PREC_* captured at create
+    bool flash = false;                    // attention core on attn_flash_kernel (any T, no score tensor)
     ~parrot_tte() {
         for (float* p : {pe, tok, spk, ln0_w, ln0_b, ln1_w, ln1_b})
             if (p) (void)hipFree(p);
@@ -1004,8 +1046,12 @@ static int build_fft(std::unique_ptr<FftLayer>& slot, const parrot_tte_cfg& c, i
         TRY(make_conv(L->out_proj, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.out_proj, nullptr));
         TRY(make_conv(L->wo, D, D, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.wo, nullptr));
     }
+    // the residual stream of an FFT block is ~10x larger than what a sub-layer adds to it: add it AFTER the sum (as the
+    // reference does, fft.py:97,99), not as the accumulator's starting value
+    L->wo->late_res = true;
     TRY(make_conv(L->conv1, D, F, c.ffn_k1, 1, (c.ffn_k1 - 1) / 2, 0, 1, PRE_NONE, 0.f, ACT_RELU, w.conv1_w, w.conv1_b));
     TRY(make_conv(L->conv2, F, D, c.ffn_k2, 1, (c.ffn_k2 - 1) / 2, 0, 1, PRE_NONE, 0.f, ACT_NONE, w.conv2_w, w.conv2_b));
+    L->conv2->late_res = true;
     TRY(upload(&L->an_w, w.attn_norm_w, D));
     TRY(upload(&L->an_b, w.attn_norm_b, D));
     TRY(upload(&L->cn_w, w.conv_norm_w, D));
@@ -1024,6 +1070,15 @@ extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, 
     if (c.dp_kernel != 3) return fail(PARROT_E_UNSUPPORTED, "tte_create: duration_predictor.kernel_size != 3 changes the sequence length in the reference (padding=1 is hard-coded, duration.py:34)");
     std::unique_ptr<parrot_tte> t(new parrot_tte());
     t->cfg = c;
+    t->scheme = default_prec();
+    {
+        // flash attention runs on the fp16 split pipe: the default scheme and the reduced-precision modes take it; the exact
+        // (f32) and bf16x6 handles keep the fp32-MFMA cores (fused for T <= 256, three kernels beyond)
+        static const bool want = [] { const char* e = getenv("PARROT_FLASH_ATTN"); return !e || atoi(e) != 0; }();
+        const bool sch_ok = t->scheme == PARROT_PREC_F16X3 || t->scheme == PARROT_PREC_BF16 || t->scheme == PARROT_PREC_F16;
+        auto hd_ok = [&](int layers, int heads) { return layers == 0 || (heads > 0 && c.d_model % heads == 0 && attn_flash_has(c.d_model / heads)); };
+        t->flash = want && sch_ok && hd_ok(c.enc_layers, c.enc_heads) && hd_ok(c.dec_layers, c.dec_heads);
+    }
     const int D = c.d_model;
     TRY(upload(&t->pe, w->pe, (size_t)c.max_len * D));
     TRY(upload(&t->tok, w->tok_emb, (size_t)c.vocab * D));
@@ -1075,7 +1130,7 @@ static TteScratch tte_scratch(const parrot_tte* t, Arena& a, int B, int T, bool 
     s.n = a.take<float>(std::max(DT, (size_t)B * c.dp_filter * T));
     s.qkv1 = a.take<float>(3 * DT);
     s.qkv2 = a.take<float>(3 * DT);
-    s.scores = a.take<float>((size_t)B * Hmax * T * T);
+    s.scores = t->flash ? nullptr : a.take<float>((size_t)B * Hmax * T * T);  // (only the three-kernel attention path materialises scores)
     s.ctx = a.take<float>(DT);
     s.o = a.take<float>(DT);
     s.h = a.take<float>(DT);
@@ -1115,7 +1170,13 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
     }
     const long DT = (long)D * T;
     static const bool fuse_attn = [] { const char* e = getenv("PARROT_FUSED_ATTN"); return !e || atoi(e) != 0; }();
-    if (fuse_attn && T <= ATTN_TMAX && hd == 128) {  // scores, softmax and context in one launch (attn.h)
+    if (t->flash) {  // any T, online softmax, no score tensor (attn.h: attn_flash_kernel)
+        AttnParams p{};
+        p.qkv = w.qkv2; p.valid = valid; p.ctx = w.ctx;
+        p.T = T; p.H = H; p.D = D; p.hd = hd;
+        p.alpha = (float)std::sqrt(1.0 / (double)hd);
+        HIP_TRY(launch_attn_flash(p, B, s));
+    } else if (fuse_attn && T <= ATTN_TMAX && hd == 128) {  // scores, softmax and context in one launch (attn.h)
         AttnParams p{};
         p.qkv = w.qkv2; p.valid = valid; p.ctx = w.ctx;
         p.T = T; p.H = H; p.D = D; p.hd = hd;

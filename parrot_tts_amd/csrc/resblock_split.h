@@ -57,7 +57,7 @@ constexpr int RBS_W = 384;  // 32-channel window (the 64-channel kernel uses hal
 // NCH = channel chunks of 16: 2 -> 32 channels, 4 waves side by side (window 384);
 //                              4 -> 64 channels, 2 (row tiles) x 2 (column halves) waves (window 192).
 template <class SCH, int NCH>
-__global__ __launch_bounds__(256, 2) void resblock_split_kernel(const ResblockSplitParams p) {
+__global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kernel(const ResblockSplitParams p) {
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = 4 / WAVES_M, NTW = 3, W = WAVES_N * NTW * 32;
     const int K = p.k;
@@ -246,14 +246,16 @@ __global__ __launch_bounds__(256, 2) void resblock_split_kernel(const ResblockSp
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? (bv[r] + R[nt][r]) * s2 : bv[r] + R[nt][r];
+            for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? bv[r] * s2 : bv[r];
         conv(p.dil[m + 1]);
+        // x = xt + x (models.py:37): the residual is added once, after the sum (one fma with the scale-back), not carried
+        // through the accumulation as the accumulator's starting value
         const float i2 = 1.f / s2;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = (SCH::XS != 1.f) ? acc[nt][r] * i2 : acc[nt][r];
+                const float v = (SCH::XS != 1.f) ? fmaf(acc[nt][r], i2, R[nt][r]) : acc[nt][r] + R[nt][r];
                 R[nt][r] = (!edge || tok[nt]) ? v : 0.f;
             }
         if (m + 2 < p.n_conv) {
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void resblock_split_kernel(const ResblockSp
 constexpr int RBS16_W = 768;
 
 template <class SCH>
-__global__ __launch_bounds__(256, 2) void resblock16_split_kernel(const ResblockSplitParams p) {
+__global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_kernel(const ResblockSplitParams p) {
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16, NT = 12, W = RBS16_W, NP = NT / 2;
     const int K = p.k, S = (K + 1) / 2;  // tap pairs per conv (even: the host only takes k = 3, 7, 11)
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void resblock16_split_kernel(const Resblock
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nt][r] = (SCH::XS != 1.f) ? (bv[r] + R[nt][r]) * s2 : bv[r] + R[nt][r];
+            for (int r = 0; r < 4; ++r) acc[nt][r] = (SCH::XS != 1.f) ? bv[r] * s2 : bv[r];
         conv(p.dil[m + 1]);
         const float i2 = 1.f / s2;
 #pragma unroll
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void resblock16_split_kernel(const Resblock
             const int t = t_base + col0 + nt * 16;
             const bool tk = !edge || (t >= 0 && t < Tlim);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R[nt][r] = tk ? ((SCH::XS != 1.f) ? acc[nt][r] * i2 : acc[nt][r]) : 0.f;
+            for (int r = 0; r < 4; ++r) R[nt][r] = tk ? ((SCH::XS != 1.f) ? fmaf(acc[nt][r], i2, R[nt][r]) : acc[nt][r] + R[nt][r]) : 0.f;
         }
         if (m + 2 < p.n_conv) {
             __syncthreads();
