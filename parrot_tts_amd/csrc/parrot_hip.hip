@@ -616,7 +616,7 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     v->fused = fused_mode();
     {
         const char* e = getenv("PARROT_MRF_STREAMS");
-        const bool on = e ? atoi(e) > 1 : true;
+        const bool on = e ? atoi(e) > 1 : false;  // measured +-0 at B = 64 (the chip is power-limited, not tail-limited): off by default
         v->mrf_streams = (on && cfg->n_kernels > 1) ? cfg->n_kernels : 1;
         if (v->mrf_streams > 1) {
             for (int j = 1; j < v->mrf_streams; ++j) HIP_TRY(hipStreamCreateWithFlags(&v->side[j], hipStreamNonBlocking));
