@@ -49,15 +49,16 @@ def save_lightning_style(path, parrot_state_dict, data_config, src_vocab_size, s
                 "hyper_parameters": {"data_config": data_config, "src_vocab_size": src_vocab_size, "src_pad_idx": src_pad_idx}}, path)
 
 
-def scan_checkpoint(cp_dir, prefix: str) -> Optional[str]:
-    """reference utils/vocoder/utils.py:62-67"""
-    found = sorted(glob.glob(os.path.join(cp_dir, prefix + "????????")))
+def scan_checkpoint(cp_dir, prefix: str, pattern: str = "????????") -> Optional[str]:
+    """reference utils/vocoder/utils.py:62-67 (``prefix + '????????'``, the training scripts' rule).  The inference driver
+    carries its own copy with ``prefix + '*'`` (utils/vocoder/inference.py:57-62): pass ``pattern='*'`` for that one."""
+    found = sorted(glob.glob(os.path.join(cp_dir, prefix + pattern)))
     return found[-1] if found else None
 
 
 def load_generator(h, checkpoint: str, device) -> CodeGenerator:
     """reference utils/vocoder/inference.py:103-109,136-137: build, load {'generator': sd}, eval, fold weight norm."""
-    path = scan_checkpoint(checkpoint, "g_") if os.path.isdir(checkpoint) else checkpoint
+    path = scan_checkpoint(checkpoint, "g_", "*") if os.path.isdir(checkpoint) else checkpoint  # the driver's own glob (inference.py:57-62)
     if not path or not os.path.isfile(path):
         raise FileNotFoundError(f"no generator checkpoint at {checkpoint}")
     g = CodeGenerator(h if isinstance(h, AttrDict) else AttrDict(h))

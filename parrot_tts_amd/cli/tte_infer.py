@@ -7,9 +7,9 @@ GPU, write <root_path>/predictions.txt in the same one-python-dict-per-line form
 ``--batch_size 1`` (default) reproduces the reference exactly (it never batches, inference.py:34).  Larger
 batches are padded like ``ParrotDataset.collate_fn`` does and, because of reference quirks Q1/Q2/Q7
 (pe[T] indexed by the padded length, conv leakage across pads), produce what the REFERENCE would produce for
-that same padded batch -- not what it produces utterance by utterance.  The audio duration field needs the
-wav files (librosa in the reference); here it is computed from the emitted units (n_units / 50 Hz) unless
---wav_durations is given and soundfile-free reading via scipy succeeds."""
+that same padded batch -- not what it produces utterance by utterance.  The `duration` field is the length of the
+utterance's wav in seconds (librosa in the reference, inference.py:62-63; scipy here) when that file exists, otherwise
+the duration of the emitted units (n_units / --units_per_second)."""
 import argparse
 import os
 
@@ -17,7 +17,14 @@ import torch
 import yaml
 
 from ..checkpoint import LitParrot
-from ..data import ParrotDataset, format_dict_line
+from ..data import ParrotDataset, format_dict_line, load_wav_int16_scale
+
+
+def wav_seconds(path, fallback: float) -> float:
+    if os.path.isfile(path):
+        audio, sr = load_wav_int16_scale(path)
+        return float(len(audio)) / float(sr)
+    return fallback
 
 
 def main(argv=None):
@@ -42,8 +49,8 @@ def main(argv=None):
             rows = model.infer(gpu)
             for i, name, codes in zip(idx, batch["ids"], rows):
                 speaker = "_".join(name.split("_")[:2])
-                results[i] = {"audio": os.path.join(audio_dir, speaker, "wavs", name + ".wav"),
-                              "hubert": " ".join(map(str, codes)), "duration": len(codes) / a.units_per_second}
+                wav = os.path.join(audio_dir, speaker, "wavs", name + ".wav")
+                results[i] = {"audio": wav, "hubert": " ".join(map(str, codes)), "duration": wav_seconds(wav, len(codes) / a.units_per_second)}
     out = os.path.join(cfg["path"]["root_path"], "predictions.txt")
     with open(out, "w") as f:
         for i in range(len(ds)):

@@ -145,3 +145,66 @@ def peak_normalize(audio: np.ndarray) -> np.ndarray:
     mag = np.abs(audio).max() if audio.size else 0.0
     tiny = np.finfo(audio.dtype if np.issubdtype(audio.dtype, np.floating) else np.float32).tiny
     return audio if mag < tiny else audio / mag
+
+
+def load_wav_int16_scale(path) -> Tuple[np.ndarray, int]:
+    """A mono wav as floats on the int16 scale, like reference utils/vocoder/dataset.py:66-78 (soundfile int16 read;
+    multi-channel files are averaged).  scipy reads PCM16 natively; float files are rescaled to that range."""
+    from scipy.io import wavfile
+    sr, data = wavfile.read(str(path))
+    if data.dtype.kind == "f":
+        data = data * 32768.0
+    elif data.dtype != np.int16:
+        data = data.astype(np.float64) / float(np.iinfo(data.dtype).max) * 32768.0
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim == 2:
+        data = data.mean(axis=1)
+    return data, int(sr)
+
+
+class CodeDataset(torch.utils.data.Dataset):
+    """Inference-side counterpart of reference utils/vocoder/dataset.py:146-251 as ``init_worker`` builds it
+    (utils/vocoder/inference.py:122-127: segment_size = -1, i.e. whole utterances): ``(audio_files, codes)`` from
+    ``parse_manifest``, the speaker table derived from the SORTED speaker names of the manifest (dataset.py:171-178),
+    and per item ``(feats, gt_audio, filename, None)`` with ``feats = {'code': (U,) int64[, 'spkr': (1,) int64]}``.
+
+    Like the reference, the units are trimmed to the ground-truth audio (``min(len(audio) // code_hop_size, len(code))``,
+    dataset.py:226-229) WHEN that audio file exists; when it does not (synthesis from predicted units only) the item keeps
+    all its units and ``gt_audio`` is None, where the reference would fail in ``load_audio``.  Training-only parts
+    (random segment sampling, the mel target, f0) are not built: the 4th element is None."""
+
+    def __init__(self, training_files, segment_size=-1, code_hop_size=320, *unused, sampling_rate=16000, multispkr=False, pad=None, **kw):
+        self.audio_files, self.codes = training_files
+        if segment_size not in (-1, None):
+            raise NotImplementedError("parrot_tts_amd.CodeDataset covers inference (segment_size = -1) only")
+        self.code_hop_size, self.sampling_rate = int(code_hop_size), sampling_rate
+        self.multispkr, self.pad = multispkr, pad
+        if self.multispkr:
+            self.id_to_spkr = sorted({parse_speaker(f, self.multispkr) for f in self.audio_files})
+            self.spkr_to_id = {k: v for v, k in enumerate(self.id_to_spkr)}
+
+    def __len__(self):
+        return len(self.audio_files)
+
+    def _get_spkr(self, idx) -> np.ndarray:
+        return np.asarray([self.spkr_to_id[parse_speaker(self.audio_files[idx], self.multispkr)]], dtype=np.int64)
+
+    def __getitem__(self, index):
+        filename = self.audio_files[index]
+        code, audio = np.asarray(self.codes[index], dtype=np.int64), None
+        if Path(filename).is_file():
+            audio, _ = load_wav_int16_scale(filename)
+            if self.pad:
+                audio = np.pad(audio, (0, self.pad - (audio.shape[-1] % self.pad)), "constant", constant_values=0)
+            audio = peak_normalize(audio / 32768.0) * 0.95          # dataset.py:217-218
+            n = min(audio.shape[0] // self.code_hop_size, code.shape[0])
+            code, audio = code[:n], torch.from_numpy(audio[: n * self.code_hop_size].astype(np.float32)).unsqueeze(0)
+        feats = {"code": code}
+        if self.multispkr:
+            feats["spkr"] = self._get_spkr(index)
+        return feats, audio, str(filename), None
+
+
+def mel_spectrogram(*args, **kwargs):
+    """reference utils/vocoder/dataset.py:44-64 is a training-loss component (and the ``_gt`` mel of the driver): out of scope."""
+    raise NotImplementedError("parrot_tts_amd covers the synthesis path only; mel_spectrogram is a training component")
