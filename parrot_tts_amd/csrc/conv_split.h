@@ -295,15 +295,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
             constexpr int PAR = decltype(par)::value;
             const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
             const int cn2 = next_chunk(cn);
+#ifndef EXP_NO_SLABLOAD
             load_slab(cn);  // (after the last chunk: a harmless re-read, stored to the idle buffer)
+#endif
             load_b(Bv[PAR], xs, 0);
 #pragma unroll
             for (int j = 0; j < KS; ++j) {  // step j: sub-slab j / K, tap j % K
                 const int cur = (PAR + j) & 1;
                 const int tq = (j + 2 < KS) ? cc : (KS == 1 ? cn2 : cn);  // step + 2 in the flat order
                 const int tj = (j + 2 < KS) ? j + 2 : (KS == 1 ? 0 : j + 2 - KS);
+#ifdef EXP_A_CONST
+                const int soff = 0;
+                (void)tq; (void)tj;
+#else
                 const int soff = (tq * KS + tj) * STEP_BYTES;
+#endif
+#ifndef EXP_NO_B
                 if (j + 1 < KS) load_b(Bv[cur ^ 1], xs + ((j + 1) / K) * SUB_BYTES, (j + 1) % K);
+#endif
 #pragma unroll
                 for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
@@ -311,9 +320,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
 #pragma unroll
                         for (int nt = 0; nt < WN; ++nt)
                             acc[mt][nt] = mfma32<SCH>(A[cur][mt][SCH::pa(t)], Bv[cur][nt][SCH::pb(t)], acc[mt][nt]);
+#ifndef EXP_NO_A
 #pragma unroll
                     for (int pc = 0; pc < NPC; ++pc)
                         if (t == SCH::last_a(pc)) load_a_piece(A[cur], pc, soff);
+#endif
                 }
             }
             // Issue order of the block (hipcc would otherwise sink every prefetch down to its first use): one
@@ -349,8 +360,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
                 for (int i = 0; i < WM; ++i) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // piece 0
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifndef EXP_NO_STORE   // (ablation builds, tools/build_exp.sh: timing only, results are wrong)
             store_slab((c + 1) & 1);
+#endif
+#ifndef EXP_NO_BARRIER
             __syncthreads();
+#endif
             cc = cn;
             cn = cn2;
         };

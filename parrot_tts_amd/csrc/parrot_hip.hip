@@ -259,6 +259,15 @@ static void split_weight(float v, int scheme, float wscale, uint16_t (&h)[3]) {
     }
 }
 
+static int g_num_cus = 256;  // (MI355X; refreshed from the device at the first *_create)
+static void query_device() {
+    static bool done = false;
+    if (done) return;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) g_num_cus = n;
+    done = true;
+}
+
 static int choose_cfg(int M, int k) {
     if (M <= 16) return 6;
     if (M <= 32) return 2;
@@ -612,6 +621,7 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     if (w->n_rb != cfg->n_stages * cfg->n_kernels * per_rb) return fail(PARROT_E_INVALID, "voc_create: wrong number of resblock convs");
     std::unique_ptr<parrot_voc> v(new parrot_voc());
     v->cfg = *cfg;
+    query_device();
     v->scheme = default_prec();
     v->fused = fused_mode();
     {
@@ -835,6 +845,12 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         p.epi = last ? epi : EPI_STORE;
         p.div = div; p.slope = 0.1f;
         p.row_len = row_len; p.row_len_mul = row_len_mul;
+        {
+            static const int stag = [] { const char* e = getenv("PARROT_STAGGER"); return e ? atoi(e) : 0; }();
+            static const int stag16 = [] { const char* e = getenv("PARROT_STAGGER16"); return e ? atoi(e) : -1; }();
+            p.stagger = (C == 16 && stag16 >= 0) ? stag16 : stag;
+            p.first_round = g_num_cus * (scheme_pieces(v->scheme) == 3 ? 2 : 3);
+        }
         ProfRec rec{};
         const double macs = (double)B * C * C * k * T * (m1 - m0);
         if (last && before_last) HIP_TRY(hipStreamWaitEvent(s, before_last, 0));  // the MRF sum is accumulated in branch order

@@ -50,7 +50,22 @@ struct ResblockSplitParams {
     float slope;
     const int32_t* row_len;
     int row_len_mul;
+    int stagger;              // phase stagger of co-resident workgroups, in units of 64 clocks per wave slot (0 = off)
+    int first_round;          // workgroups of the launch's first round (CUs x workgroups per CU): only they are delayed
 };
+
+// Co-resident workgroups of these kernels start together, take the same time and therefore stay in LOCKSTEP: all of them
+// convert (VALU busy, matrix pipe idle) and then all of them multiply (matrix pipe busy, VALU idle).  Delaying the first
+// round's workgroups by their hardware wave slot (HW_ID.WAVE_ID: the co-resident waves of a SIMD have different slots)
+// shifts the phases once; every later workgroup inherits the phase of the one it replaces.
+__device__ __forceinline__ void phase_stagger(int units, int first_round) {
+    if (units > 0 && (int)blockIdx.x < first_round) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        const int slot = hwid & 15;
+        for (int i = 0; i < slot * units; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
+}
 
 constexpr int RBS_W = 384;  // 32-channel window (the 64-channel kernel uses half: the same 72 KiB of LDS)
 
@@ -61,7 +76,9 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kern
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = 4 / WAVES_M, NTW = 3, W = WAVES_N * NTW * 32;
     const int K = p.k;
-    constexpr int CH_BYTES = W * 32, PIECE_BYTES = NCH * CH_BYTES;  // [piece][chunk][col][16 ch] bf16
+    // operand buffer: [piece][chunk][octet][col][8 channels]: 16 bytes per (column, octet), columns contiguous -- both the
+    // 16-byte stores of write_p and the ds_read_b128 fragment reads at any tap shift walk consecutive addresses across lanes
+    constexpr int OCT_BYTES = W * 16, CH_BYTES = 2 * OCT_BYTES, PIECE_BYTES = NCH * CH_BYTES;
     static_assert(NCH == 2 || NCH == 4, "32 or 64 channels");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // NP * PIECE_BYTES
 
@@ -77,6 +94,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kern
     const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
     const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);  // window not fully inside the row
+    phase_stagger(p.stagger, p.first_round);
 
     int col[NTW];   // this lane's window column per tile
     bool tok[NTW];  // ... inside the sequence
@@ -110,31 +128,34 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kern
     auto write_p = [&](const f32x16 (&v)[NTW], float mul) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const int swz = (col[nt] >> 3) & 1;
+            const float m2 = (SCH::XS != 1.f) ? mul * p.slope : p.slope;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q) {
+                unsigned qq[2][2][NPC];  // [octet g][pair e][piece]
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    unsigned qq[2][NPC];
+                for (int g = 0; g < 2; ++g)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        float v0 = v[nt][8 * q + 4 * g + 2 * e], v1 = v[nt][8 * q + 4 * g + 2 * e + 1];
-                        if constexpr (SCH::XS != 1.f) {
-                            v0 *= mul;
-                            v1 *= mul;
-                        }
-                        v0 = max_nc(v0, v0 * p.slope);
-                        v1 = max_nc(v1, v1 * p.slope);
+                        const f32x2 vv = {v[nt][8 * q + 4 * g + 2 * e], v[nt][8 * q + 4 * g + 2 * e + 1]};
+                        const f32x2 a = (SCH::XS != 1.f) ? vv * mul : vv, bq = vv * m2;  // lrelu(c v) = max(c v, c slope v): packed multiplies
+                        float v0 = max_nc(a[0], bq[0]), v1 = max_nc(a[1], bq[1]);
                         if (edge) {
                             v0 = tok[nt] ? v0 : 0.f;
                             v1 = tok[nt] ? v1 : 0.f;
                         }
-                        SCH::split(v0, v1, qq[e]);
+                        SCH::split(v0, v1, qq[g][e]);
                     }
-                    char* dst = smem_raw + (2 * wm + q) * CH_BYTES + col[nt] * 32 + ((g ^ swz) * 16) + 8 * half;
+                // A lane holds 4 of the 8 channels of both octets of this column (the other 4 sit in lane ^ 32).  Swap the
+                // halves across the two half-waves (v_permlane32_swap): lane (col, half h) then owns octet h completely and
+                // stores 16 contiguous bytes -- 8-byte stores at a 32-byte lane stride cost 4.7 -> 4.1 ms in bank conflicts.
+                char* dst = smem_raw + (2 * wm + q) * CH_BYTES + half * OCT_BYTES + col[nt] * 16;
 #pragma unroll
-                    for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<uint2*>(dst + pc * PIECE_BYTES) = uint2{qq[0][pc], qq[1][pc]};
+                for (int pc = 0; pc < NPC; ++pc) {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(qq[0][0][pc], qq[1][0][pc], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(qq[0][1][pc], qq[1][1][pc], false, false);
+                    *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES) = uint4{r0[0], r1[0], r0[1], r1[1]};
                 }
+            }
         }
     };
 
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kern
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int cc = min(max(col[nt] + shift, 0), W - 1);  // clamped: only garbage columns ever read a clamped one
-            const char* src = smem_raw + ch * CH_BYTES + cc * 32 + ((half ^ ((cc >> 3) & 1)) * 16);
+            const char* src = smem_raw + ch * CH_BYTES + half * OCT_BYTES + cc * 16;
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) bb[nt][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
@@ -189,8 +210,10 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kern
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int set = ch & 1;
+#ifndef EXP_RB_NO_B
                 if (ch + 1 < NCH) load_b(Bv[set ^ 1], ch + 1, shift);
                 else load_b(Bv[set ^ 1], 0, shift + dil);
+#endif
                 const int nx = (ch + 2 < NCH) ? gbase + (ch + 2) * K + j : n0 + (ch + 2 - NCH) * K;  // two steps ahead
 #pragma unroll
                 for (int t = 0; t < NTERM; ++t) {
@@ -239,7 +262,9 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kern
             for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? bv[r] * s1 : bv[r];
         conv(p.dil[m]);
         __syncthreads();  // every wave is done reading P
+#ifndef EXP_RB_NO_WRITE
         write_p(acc, 1.f / p.wsc[m]);  // P = split(lrelu(h)), masked: acc / s1 * XS
+#endif
         __syncthreads();
         // R = conv_1(P) + b2 + R
         bias_rows(p.bias[m + 1], bv);
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16, NT = 12, W = RBS16_W, NP = NT / 2;
     const int K = p.k, S = (K + 1) / 2;  // tap pairs per conv (even: the host only takes k = 3, 7, 11)
-    constexpr int PIECE_BYTES = W * 32;  // [piece][col][16 ch] bf16
+    constexpr int OCT_BYTES = W * 16, PIECE_BYTES = 2 * OCT_BYTES;  // [piece][octet][col][8 channels] (see resblock_split_kernel)
     static_assert(4 * NT * 16 == W, "4 waves x NT tiles cover the window");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // NPC * PIECE_BYTES
 
@@ -326,6 +351,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
     const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);
     const int col0 = wave * (NT * 16) + l15;  // this lane's window column in tile 0 (tile nt adds 16 nt)
+    phase_stagger(p.stagger, p.first_round);
 
     f32x4 R[NT], acc[NT];
     {
@@ -343,30 +369,37 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
         }
     }
     auto write_p = [&](const f32x4 (&v)[NT], float mul) __attribute__((always_inline)) {
+        const float m2 = (SCH::XS != 1.f) ? mul * p.slope : p.slope;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int c = col0 + nt * 16;
-            const int t = t_base + c;
-            const bool tk = t >= 0 && t < Tlim;
-            unsigned qq[2][NPC];
+        for (int np = 0; np < NT; np += 2) {  // tile pairs: lane groups with even g4 end up owning tile np's octet, odd ones tile np+1's
+            unsigned qq[2][2][NPC];           // [tile of the pair][pair e][piece]
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float v0 = v[nt][2 * e], v1 = v[nt][2 * e + 1];
-                if constexpr (SCH::XS != 1.f) {
-                    v0 *= mul;
-                    v1 *= mul;
+            for (int u = 0; u < 2; ++u) {
+                const int c = col0 + (np + u) * 16;
+                const int t = t_base + c;
+                const bool tk = t >= 0 && t < Tlim;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f32x2 vv = {v[np + u][2 * e], v[np + u][2 * e + 1]};
+                    const f32x2 a = (SCH::XS != 1.f) ? vv * mul : vv, bq = vv * m2;
+                    float v0 = max_nc(a[0], bq[0]), v1 = max_nc(a[1], bq[1]);
+                    if (edge) {
+                        v0 = tk ? v0 : 0.f;
+                        v1 = tk ? v1 : 0.f;
+                    }
+                    SCH::split(v0, v1, qq[u][e]);
                 }
-                v0 = max_nc(v0, v0 * p.slope);
-                v1 = max_nc(v1, v1 * p.slope);
-                if (edge) {
-                    v0 = tk ? v0 : 0.f;
-                    v1 = tk ? v1 : 0.f;
-                }
-                SCH::split(v0, v1, qq[e]);
             }
-            char* dst = smem_raw + c * 32 + (((g4 >> 1) ^ ((c >> 2) & 1)) * 16) + 8 * (g4 & 1);
+            // a lane holds 4 of the 8 channels of an octet (the other 4 sit in lane ^ 16): v_permlane16_swap gives the even
+            // 16-lane rows the whole octet of tile np and the odd rows that of tile np + 1 -> one 16-byte store per lane
+            const int c = col0 + (np + (g4 & 1)) * 16;
+            char* dst = smem_raw + (g4 >> 1) * OCT_BYTES + c * 16;
 #pragma unroll
-            for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<uint2*>(dst + pc * PIECE_BYTES) = uint2{qq[0][pc], qq[1][pc]};
+            for (int pc = 0; pc < NPC; ++pc) {
+                const auto r0 = __builtin_amdgcn_permlane16_swap(qq[0][0][pc], qq[1][0][pc], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(qq[0][1][pc], qq[1][1][pc], false, false);
+                *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES) = uint4{r0[0], r1[0], r0[1], r1[1]};
+            }
         }
     };
 
@@ -394,7 +427,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int cc = min(max(col0 + (2 * pr + q) * 16 + shift, 0), W - 1);
-            const char* src = smem_raw + cc * 32 + (((g4 & 1) ^ ((cc >> 2) & 1)) * 16);
+            const char* src = smem_raw + (g4 & 1) * OCT_BYTES + cc * 16;
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) bb[q][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
@@ -410,8 +443,10 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
 #pragma unroll
                 for (int pr = 0; pr < NP; ++pr) {
                     const int cur = pr & 1;  // NP is even: every step starts on operand set 0
+#ifndef EXP_RB_NO_B
                     if (pr + 1 < NP) load_b(Bv[cur ^ 1], pr + 1, tpd + 2 * s * dil);
                     else load_b(Bv[cur ^ 1], 0, tpd + 2 * (s + 1) * dil);  // (after the last step: discarded)
+#endif
 #pragma unroll
                     for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
@@ -455,7 +490,9 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
             for (int r = 0; r < 4; ++r) acc[nt][r] = bv[r];
         conv(p.dil[m]);
         __syncthreads();
+#ifndef EXP_RB_NO_WRITE
         write_p(acc, 1.f / p.wsc[m]);
+#endif
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + 1][4 * g4 + r];
