@@ -1,0 +1,288 @@
+// conv_split16.h -- the split-scheme Conv1d implicit GEMM of conv_split.h on the 16x16x32 MFMA shape
+// (v_mfma_f32_16x16x32_{f16,bf16}) for the wide MRF / FFN layers (C_in a multiple of 32, plain convs).
+//
+// Why another shape.  The split kernels are POWER limited, not issue limited (with random operands a
+// pure MFMA stream sustains ~1.7 PF at whatever duty cycle; the clock follows the energy per instruction).  What is left
+// to win is energy per useful FLOP, and the 16x16x32 shape spends less of it than 32x32x16:
+//   * one operand fragment (64 lanes x 8 halves) now spans K = 32 instead of 16: a 64x64 wave tile is 4x4 tiles fed by
+//     4 + 4 fragments per 32-deep k-step -- HALF the LDS / L1 operand bytes per MAC of the 2x2 tiling of 32x32x16;
+//   * a quarter of the accumulator registers are read and written per instruction (tools/probes/mfma_power.hip: +7 %
+//     sustained rate for the bare instruction stream).
+// Data path: CI = 32 input channels per chunk = one k-step per tap.
+//   * B (activations): global -> registers -> (leaky-ReLU, scale, split) -> LDS as [piece][octet 0..3][column][8 channels]
+//     (16 bytes per (column, octet), columns contiguous): a lane (column l & 15, octet l >> 4) reads its fragment at any
+//     tap shift with one ds_read_b128, 16 lanes on consecutive addresses -- conflict free without swizzling; stores too.
+//     Double buffered, one barrier per chunk.  One fragment set, refilled in place during the last MFMA group of a step.
+//   * A (weights): host-packed [m16 tile][chunk * k + tap][piece][lane][8 halves] (lane = row l & 15, channels 8 (l >> 4)..),
+//     one buffer_load_dwordx4 per (m16 tile, piece) per step, re-fetched in place right after the row tile's MFMA group.
+#pragma once
+#include "conv_split.h"
+
+namespace parrot {
+
+template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void conv_split16_kernel(const ConvParams p) {
+    static_assert(K > 0, "tap count is a template parameter");
+    constexpr int NPC = SCH::NP, NTERM = SCH::NT;
+    constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    constexpr int COLS = (BN + CONV_HALO + 63) / 64 * 64;  // staged columns per chunk
+    constexpr int OCT_BYTES = COLS * 16, PIECE_BYTES = 4 * OCT_BYTES, BUF_BYTES = NPC * PIECE_BYTES;
+    constexpr int LIVE = COLS * 4;                   // (octet, column) items per chunk
+    constexpr int ITEMS = (LIVE + NT - 1) / NT;
+    constexpr int STEP_BYTES = NPC * 1024;
+    static_assert(LIVE % NT == 0, "every thread stages the same number of items");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [2][NP][4 octets][COLS][8 halves]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int g4 = lane >> 4, l15 = lane & 15;
+
+    // XCD-aware block order (see conv_split.h): the M-blocks of one column tile sit 8 workgroup ids apart
+    const int n_mb = (p.M + BM - 1) / BM;
+    const int grp8 = blockIdx.x / (8 * n_mb), within = blockIdx.x - grp8 * (8 * n_mb);
+    const int mblock = within >> 3;
+    const int tile_id = grp8 * 8 + (within & 7);
+    if (tile_id >= p.tiles_n * p.B) return;
+    const int b = tile_id / p.tiles_n;
+    const int tn0 = tile_id - b * p.tiles_n;
+    const int t0 = tn0 * BN;
+    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;
+    const int W = BN + (K - 1) * p.dil;
+    const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride;
+
+    // ---- slab fetch: buffer-addressed, out-of-row / out-of-reach columns read 0 (= the zero padding) ----------------
+    const size_t xaddr = reinterpret_cast<size_t>(xb);
+    const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((size_t)x_hi << 32) | x_lo), 0, 0x7fffffff, 0x00020000);
+    const int row_bytes = p.Tin * 4;
+    const float slope = (p.pre == PRE_LRELU) ? p.pre_slope : 1.f;
+    int voff[ITEMS], soct[ITEMS];
+    static_for<ITEMS>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int item = tid + NT * i;
+        const int so = item / COLS;  // octet (wave-uniform: COLS is a multiple of 64)
+        const int col = item - so * COLS;
+        const int tin = t0 - p.pad_left + col;
+        voff[i] = (col < W && tin >= 0 && tin < Tlim) ? tin * 4 : (int)0x80000000;
+        soct[i] = __builtin_amdgcn_readfirstlane(so * 8) * row_bytes;
+    });
+    float stage[ITEMS][8];
+    auto load_slab = [&](int c) __attribute__((always_inline)) {
+        const int cbase = c * 32 * row_bytes;
+        static_for<ITEMS>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                stage[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff[i], cbase + soct[i] + e * row_bytes, 0));
+        });
+    };
+    auto store_slab = [&](int buf) __attribute__((always_inline)) {
+        char* dst = smem_raw + buf * BUF_BYTES;
+        static_for<ITEMS>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int item = tid + NT * i;
+            unsigned q[4][NPC];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                SCH::split(pre_scale<SCH>(stage[i][2 * e], slope), pre_scale<SCH>(stage[i][2 * e + 1], slope), q[e]);
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc)  // item = octet * COLS + column: consecutive lanes, consecutive 16-byte slots
+                *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES + item * 16) = uint4{q[0][pc], q[1][pc], q[2][pc], q[3][pc]};
+        });
+    };
+
+    // ---- accumulators: C/D layout of 16x16 MFMA: column l & 15, rows 4 (l >> 4) + r --------------------------------
+    f32x4 acc[TM][TN];
+    const int m_wave = mblock * BM + wm * TM * 16;
+    const int n_wave = t0 + wn * TN * 16;
+    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
+    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    const bool fold_res = rb != nullptr && p.act == ACT_NONE && p.fold_res != 0;
+    {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            float bs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bs[r] = p.bias ? p.bias[min(m_wave + tm * 16 + 4 * g4 + r, p.M - 1)] : 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = n_wave + tn * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m_wave + tm * 16 + 4 * g4 + r;
+                    const float rv = fold_res ? rb[(n < p.Ncols && m < p.M) ? m * p.Tout + n : 0] : 0.f;
+                    acc[tm][tn][r] = (rv + bs[r]) * p.acc_scale;
+                }
+            }
+        }
+    }
+
+    // ---- weight stream ---------------------------------------------------------------------------------------------
+    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(p.wfrag));
+    const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<size_t>(p.wfrag) >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)w_hi << 32) | w_lo), 0, 0x7fffffff, 0x00020000);
+    int abase[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+        abase[tm] = __builtin_amdgcn_readfirstlane((int)((mblock * (BM / 16) + wm * TM + tm) * p.n_it * STEP_BYTES));
+    const unsigned lane16 = lane * 16;
+    // ONE register set per operand, refilled in place: a step's MFMAs run row tile by row tile, so A[tm] is dead after its
+    // group (NTERM * TN MFMAs) and is re-fetched for the next step right there (3 groups = 36+ MFMAs ahead of its next use);
+    // the column fragments are re-read from LDS during the step's last group, each right after its last MFMA.
+    s16x8 A[TM][NPC], Bv[TN][NPC];
+    auto load_a_tile = [&](s16x8 (&a)[NPC], int tm, int step) __attribute__((always_inline)) {
+        const int soff = step * STEP_BYTES;
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc)
+            a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, abase[tm] + soff, 0));
+    };
+    const int colbase = wn * TN * 16 + l15;
+    auto load_b_tile = [&](s16x8 (&bb)[NPC], const char* __restrict__ xs, int tn, int tap) __attribute__((always_inline)) {
+        const char* src = xs + g4 * OCT_BYTES + (colbase + tn * 16 + tap * p.dil) * 16;
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) bb[pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
+    };
+
+    const int nchunks = p.nchunks;  // chunks of 32 channels
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) load_a_tile(A[tm], tm, 0);
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {  // one chunk = K straight-line steps
+        const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
+        const bool more = c + 1 < nchunks;
+        if (more) load_slab(c + 1);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) load_b_tile(Bv[tn], xs, tn, 0);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                for (int t = 0; t < NTERM; ++t)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        acc[tm][tn] = mfma16<SCH>(A[tm][SCH::pa(t)], Bv[tn][SCH::pb(t)], acc[tm][tn]);
+                        if (tm == TM - 1 && t == NTERM - 1 && j + 1 < K) load_b_tile(Bv[tn], xs, tn, j + 1);
+                    }
+                load_a_tile(A[tm], tm, c * K + j + 1);  // (past the last step: the stream is padded by one step)
+            }
+        }
+        // issue order: one memory instruction in the shadow of each MFMA -- in the chunk's first step the slab loads, a row
+        // tile's weight refetch right after its group, a column tile's fragment refill right after its last MFMA
+        constexpr int PER_TM = NTERM * TN;
+#pragma unroll
+        for (int i = 0; i < NPC * TN; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            int slab_left = (j == 0) ? ITEMS * 8 : 0;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                for (int m = 0; m < PER_TM; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (tm == TM - 1 && m >= PER_TM - TN && j + 1 < K) {
+#pragma unroll
+                        for (int i = 0; i < NPC; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    } else if (slab_left > 0) {
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        --slab_left;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NPC; ++i) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_slab((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (plain convs only): scale back, late residual / activation / MRF accumulation modes ------------------
+    const bool late_res = rb != nullptr && !fold_res;
+    const bool has_acc = p.epi != EPI_STORE;
+    const bool do_div = p.epi == EPI_ADD_DIV;
+    const float act_lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n_wave + tn * 16 + l15;
+            int off[4];
+            float rv[4], yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_wave + tm * 16 + 4 * g4 + r;
+                off[r] = (n < p.Ncols && m < p.M) ? m * p.Tout + n : -1;
+                rv[r] = 0.f;
+                yv[r] = 0.f;
+            }
+            if (late_res) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rv[r] = rb[off[r] < 0 ? 0 : off[r]];
+            }
+            if (has_acc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[r] = yb[off[r] < 0 ? 0 : off[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = yv[r] + (fmaxf(acc[tm][tn][r] * p.out_scale, act_lo) + rv[r]);
+                if (do_div) v = v / p.div;
+                if (off[r] >= 0) yb[off[r]] = v;
+            }
+        }
+}
+
+template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K>
+inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16, COLS = (BN + CONV_HALO + 63) / 64 * 64;
+    const size_t lds = (size_t)2 * SCH::NP * 4 * COLS * 16;
+    auto kern = conv_split16_kernel<SCH, WAVES_M, WAVES_N, TM, TN, K>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const unsigned tiles = (unsigned)p.tiles_n * p.B, n_mb = (p.M + BM - 1) / BM;
+    hipLaunchKernelGGL(kern, dim3((tiles + 7) / 8 * 8 * n_mb), dim3(WAVES_M * WAVES_N * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+// tile variants: 0 = 128 x 128 (waves 2x2, wave tile 64x64 = 4x4 MFMA tiles), 1 = 64 x 192 (waves 1x4, wave tile 64x48)
+inline void split16_tile(int variant, int& bm, int& bn) {
+    bm = variant ? 64 : 128;
+    bn = variant ? 192 : 128;
+}
+// (k = 3: three steps per 32-channel chunk do not amortise the larger slab -- measured 3-6 % slower than conv_split_kernel)
+inline bool split16_has(int scheme, int k) { return scheme == SchF16x3::ID && (k == 7 || k == 9 || k == 11); }
+template <class SCH>
+inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStream_t s) {
+    if (variant) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 7>(p, s);
+            case 9: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 9>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 11>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    switch (p.k) {
+        case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 7>(p, s);
+        case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 9>(p, s);
+        case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 11>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+inline hipError_t launch_conv_split16(int scheme, int variant, const ConvParams& p, hipStream_t s) {
+    if (scheme == SchF16x3::ID) return launch_conv_split16_s<SchF16x3>(variant, p, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace parrot

@@ -16,6 +16,7 @@
 
 #include "attn.h"
 #include "conv_split.h"
+#include "conv_split16.h"
 #include "conv_mfma.h"
 #include "conv_mfma16.h"
 #include "conv_valu.h"
@@ -153,6 +154,7 @@ struct parrot_conv {
     uint16_t* wfrag16 = nullptr;  // [m_tile][chunk*tap][piece][lane][8 x 16 bit]
     int n_it16 = 0;
     float wscale = 1.f;        // power-of-two weight scale inside the fp16 pieces (1 for bf16 schemes)
+    bool mfma16 = false;       // split plan packed for conv_split16_kernel (16x16x32 MFMA, 32-channel chunks)
     bool late_res = false;     // add the residual in the epilogue instead of folding it into the accumulator init (TTE layers)
     int valu_kind = 0;         // 1: conv1_valu_kernel<7>, 2: convt_valu_kernel<16,4,2,1> (conv_valu.h); weights in their original layout
     float* wraw = nullptr;
@@ -280,7 +282,11 @@ static bool valu_kernels_enabled() {
     static const bool on = [] { const char* e = getenv("PARROT_VALU_KERNELS"); return !e || atoi(e) != 0; }();
     return on;
 }
-static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, const float* w, const float* bias) {
+static bool mfma16_enabled() {
+    static const bool on = [] { const char* e = getenv("PARROT_MFMA16"); return !e || atoi(e) != 0; }();
+    return on;
+}
+static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, const float* w, const float* bias, bool allow16 = true) {
     if (!out || !d || !w) return fail(PARROT_E_INVALID, "conv_create: null argument");
     if (d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->dilation <= 0 || groups <= 0 || d->c_in % groups || d->c_out % groups)
         return fail(PARROT_E_INVALID, "conv_create: bad dimensions");
@@ -391,14 +397,40 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
         c->cfg = (c->Mg <= 32) ? 2 : (c->Mg <= 64) ? 1 : 0;  // exact-kernel tile ids with the same block shapes
         const TileCfg t16 = tile_cfg(c->cfg);
         if (groups > 1 && c->Mg % t16.bm) return fail(PARROT_E_UNSUPPORTED, "conv_create: rows per group must be a multiple of the tile height");
+        if (f16) c->wscale = f16_weight_scale(w, (size_t)d->c_in / groups * d->c_out * d->k);
+        // wide plain convs: the 16x16x32 kernel (conv_split16.h): 32-channel chunks, [m16 tile][chunk*tap][piece][lane][8]
+        c->mfma16 = allow16 && mfma16_enabled() && split16_has(want_prec, c->kk) && !d->transposed && groups == 1 && c->Cin % 32 == 0 && c->M >= 64;
+        size_t n16 = 0;
+        std::vector<uint16_t> pk16;
+        if (c->mfma16) {
+            int bm16, bn16;
+            split16_tile(c->M >= 128 ? 0 : 1, bm16, bn16);
+            c->nchunks = c->Cin / 32;
+            c->n_it16 = c->nchunks * c->kk;
+            const int mt = (c->M + bm16 - 1) / bm16 * (bm16 / 16);
+            const size_t step_h = (size_t)NP * 512;
+            n16 = ((size_t)mt * c->n_it16 + 1) * step_h;
+            if (n16 * sizeof(uint16_t) >= ((size_t)1 << 31)) return fail(PARROT_E_UNSUPPORTED, "conv_create: packed weight stream larger than 2 GiB");
+            pk16.assign(n16, 0);
+            for (int m16 = 0; m16 < mt; ++m16)
+                for (int ch = 0; ch < c->nchunks; ++ch)
+                    for (int j = 0; j < c->kk; ++j) {
+                        uint16_t* g = pk16.data() + ((size_t)m16 * c->n_it16 + (size_t)ch * c->kk + j) * step_h;
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                uint16_t h[3];
+                                split_weight(wval(m16 * 16 + (lane & 15), ch * 32 + 8 * (lane >> 4) + e, j), want_prec, c->wscale, h);
+                                for (int pc = 0; pc < NP; ++pc) g[pc * 512 + lane * 8 + e] = h[pc];
+                            }
+                    }
+        } else {
         c->nchunks = (c->Cin + 15) / 16;
         c->n_it16 = c->nchunks * c->kk;
         const int mt16 = (c->M + t16.bm - 1) / t16.bm * (t16.bm / 32);
         const size_t step_h = (size_t)NP * 512;  // 16-bit words per step: NP pieces x 64 lanes x 8
-        const size_t n16 = ((size_t)mt16 * c->n_it16 + 1) * step_h;  // (+1 pad step)
+        n16 = ((size_t)mt16 * c->n_it16 + 1) * step_h;  // (+1 pad step)
         if (n16 * sizeof(uint16_t) >= ((size_t)1 << 31)) return fail(PARROT_E_UNSUPPORTED, "conv_create: packed weight stream larger than 2 GiB");
-        if (f16) c->wscale = f16_weight_scale(w, (size_t)d->c_in / groups * d->c_out * d->k);
-        std::vector<uint16_t> pk16(n16, 0);
+        pk16.assign(n16, 0);
         for (int mt = 0; mt < mt16; ++mt)
             for (int ch = 0; ch < c->nchunks; ++ch)
                 for (int j = 0; j < c->kk; ++j) {
@@ -410,6 +442,7 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
                             for (int pc = 0; pc < NP; ++pc) g[pc * 512 + lane * 8 + e] = h[pc];
                         }
                 }
+        }
         HIP_TRY(hipMalloc((void**)&c->wfrag16, n16 * sizeof(uint16_t)));
         HIP_TRY(hipMemcpy(c->wfrag16, pk16.data(), n16 * sizeof(uint16_t), hipMemcpyHostToDevice));
     } else {
@@ -491,7 +524,10 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     }
     TileCfg t = tile_cfg(cfg);
     int variant16 = 0;
-    if (c->prec >= 1) {
+    if (c->mfma16) {
+        variant16 = c->M >= 128 ? 0 : 1;
+        split16_tile(variant16, t.bm, t.bn);
+    } else if (c->prec >= 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
         // better (76 vs 61 TF on the qkv projection); every other layer is faster on the 64x64 wave tile
         // (and so are sequences of <= 64 steps -- the TTE encoder side -- which would leave half of a 128-column tile empty)
@@ -504,10 +540,11 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         // algorithmic work of the layer (real taps only; DESIGN.md "roofline accounting")
         const double macs = (double)B * c->d.c_out * c->Cin * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         const double elems = (double)B * ((double)c->d.c_in * Tin + (double)c->Cout * Tout * (1 + (res ? 1 : 0) + (epi != EPI_STORE ? 1 : 0)));
-        const int row = (c->prec >= 1) ? (variant16 >= 2 ? NUM_TILE_CFGS + 1 + variant16 : NUM_TILE_CFGS + cfg) : cfg;  // split rows follow the exact ones
+        const int row = c->mfma16 ? NUM_TILE_CFGS + 9 + variant16
+                                  : (c->prec >= 1) ? (variant16 >= 2 ? NUM_TILE_CFGS + 1 + variant16 : NUM_TILE_CFGS + cfg) : cfg;  // split rows follow the exact ones
         TRY(prof_open(rec, row, 2.0 * macs, 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k), s));
     }
-    HIP_TRY(c->prec >= 1 ? launch_conv_split(c->prec, variant16, p, s) : (cfg == 6 ? launch_conv_mfma16(p, s) : launch_conv(cfg, p, s)));
+    HIP_TRY(c->mfma16 ? launch_conv_split16(c->prec, variant16, p, s) : c->prec >= 1 ? launch_conv_split(c->prec, variant16, p, s) : (cfg == 6 ? launch_conv_mfma16(p, s) : launch_conv(cfg, p, s)));
     if (c->d.act == ACT_TANH) {  // dense (B, Cout, Tout) output assumed for the tanh layers (conv_post)
         const size_t n = (size_t)B * c->Cout * Tout;
         hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n);
@@ -598,12 +635,12 @@ static int upload(float** dst, const float* src, size_t n) {
 }
 
 static int make_conv(std::unique_ptr<parrot_conv>& slot, int cin, int cout, int k, int dil, int pad, int transposed, int stride,
-                     int pre, float slope, int act, const float* w, const float* b, int groups = 1) {
+                     int pre, float slope, int act, const float* w, const float* b, int groups = 1, bool allow16 = true) {
     parrot_conv_desc d{};
     d.c_in = cin; d.c_out = cout; d.k = k; d.dilation = dil; d.padding = pad; d.transposed = transposed; d.stride = stride;
     d.pre_act = pre; d.pre_slope = slope; d.act = act; d.tile_cfg = -1; d.precision = -1;
     parrot_conv* c = nullptr;
-    TRY(conv_build(&c, &d, groups, w, b));
+    TRY(conv_build(&c, &d, groups, w, b, allow16));
     slot.reset(c);
     return PARROT_OK;
 }
@@ -657,17 +694,19 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
         TRY(make_conv(v->ups[i], cin, cout, k, 1, (k - u) / 2, 1, u, PRE_LRELU, 0.1f, ACT_NONE, w->ups_w[i], w->ups_b[i]));
         for (int j = 0; j < cfg->n_kernels; ++j) {
             const int rk = cfg->resblock_kernel_sizes[j];
+            // (blocks that run on the fused pair kernels reuse their plans' 32x32x16 weight streams: keep that packing)
+            const bool a16 = !(v->fused != 0 && cfg->resblock_type == 1 && resblock_split_has(cout, rk) && per_rb <= RBS_MAX_CONVS);
             for (int m = 0; m < cfg->n_dil; ++m) {
                 const int dl = cfg->resblock_dilation_sizes[j][m];
                 const int base = (i * cfg->n_kernels + j) * per_rb;
                 if (cfg->resblock_type == 1) {
                     TRY(make_conv(v->rb[base + 2 * m], cout, cout, rk, dl, (rk * dl - dl) / 2, 0, 1, PRE_LRELU, 0.1f, ACT_NONE,
-                                  w->rb_w[base + 2 * m], w->rb_b[base + 2 * m]));
+                                  w->rb_w[base + 2 * m], w->rb_b[base + 2 * m], 1, a16));
                     TRY(make_conv(v->rb[base + 2 * m + 1], cout, cout, rk, 1, (rk - 1) / 2, 0, 1, PRE_LRELU, 0.1f, ACT_NONE,
-                                  w->rb_w[base + 2 * m + 1], w->rb_b[base + 2 * m + 1]));
+                                  w->rb_w[base + 2 * m + 1], w->rb_b[base + 2 * m + 1], 1, a16));
                 } else {
                     TRY(make_conv(v->rb[base + m], cout, cout, rk, dl, (rk * dl - dl) / 2, 0, 1, PRE_LRELU, 0.1f, ACT_NONE,
-                                  w->rb_w[base + m], w->rb_b[base + m]));
+                                  w->rb_w[base + m], w->rb_b[base + m], 1, a16));
                 }
             }
         }
@@ -690,7 +729,7 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
                 bool ok = true;
                 for (int q = 0; q < per_rb; ++q) {
                     const parrot_conv* pc = v->rb[base + q].get();
-                    ok = ok && pc->prec == v->scheme && pc->wfrag16 && pc->nchunks == C / 16 && (C / 32) * pc->n_it16 == steps && pc->M == C &&
+                    ok = ok && pc->prec == v->scheme && !pc->mfma16 && pc->wfrag16 && pc->nchunks == C / 16 && (C / 32) * pc->n_it16 == steps && pc->M == C &&
                          tile_cfg(pc->cfg).bm == C;
                 }
                 if (!ok) continue;

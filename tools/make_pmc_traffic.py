@@ -19,6 +19,9 @@ def norm(name: str) -> str:
     m = re.match(r"(conv_split_kernel<Sch\w+,\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
     if m:
         return m.group(1) + ">"
+    m = re.match(r"(conv_split16_kernel<Sch\w+,\d+,\d+,\d+,\d+),\d+>", name)
+    if m:
+        return m.group(1) + ">"
     if name == "conv1_valu7_vec_kernel":
         return "conv1_valu_kernel"
     name = re.sub(r"^resblock_split_kernel<(Sch\w+),\d+>$", r"resblock_split_kernel<\1>", name)
