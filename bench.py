@@ -247,7 +247,7 @@ def main():
         value = n_samples_step / (ms / 1e3)
         dom = rows[0]
         traffic, traffic_src = pmc_traffic(dom["kernel"])
-        split = "_split_kernel" in dom["kernel"]
+        split = "_split" in dom["kernel"]
         n_mfma = SCHEMES[a.precision][1]
         peak = MFMA16_PEAK_TFLOPS / n_mfma if split else FP32_MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
