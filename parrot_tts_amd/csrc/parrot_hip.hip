@@ -22,6 +22,7 @@
 #include "conv_valu.h"
 #include "kernels_misc.h"
 #include "resblock_split.h"
+#include "resblock_split16.h"
 #include "resblock_fused.h"
 
 using namespace parrot;
@@ -603,6 +604,8 @@ struct parrot_voc {
     std::vector<std::unique_ptr<parrot_conv>> ups, rb;
     std::vector<uint16_t*> rb_stream;  // per (stage, kernel): concatenated split weight stream of the block (or null)
     std::vector<float> rb_wsc;         // per resblock conv: weight scale inside that stream (fp16 schemes; else 1)
+    std::vector<int> rb_kind;          // per (stage, kernel): 0 = resblock_split.h kernels, 1 = resblock_split16_kernel
+    std::vector<size_t> rb_conv_halves;  // 16-bit words per conv in that stream
     int up_total = 1;
     int scheme = 0;                    // PARROT_PREC_* captured at create (immutable afterwards)
     int fused = 2;                     // fused-ResBlock mode captured at create
@@ -611,6 +614,7 @@ struct parrot_voc {
     // accumulating launches are ordered with events (sum order j = 0, 1, 2 as models.py:100-106).  One branch's
     // launch tails, prologues and epilogues then overlap another branch's main loops.
     int mrf_streams = 1;
+    bool mrf_auto = true;
     hipStream_t side[PARROT_MAX_KERNELS] = {};
     hipEvent_t ev_fork = nullptr, ev_last[PARROT_MAX_KERNELS] = {};
     ~parrot_voc() {
@@ -663,7 +667,11 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     v->fused = fused_mode();
     {
         const char* e = getenv("PARROT_MRF_STREAMS");
-        const bool on = e ? atoi(e) > 1 : false;  // measured +-0 at B = 64 (the chip is power-limited, not tail-limited): off by default
+        // default "auto": concurrent branches for small batches (B = 1 ... 16: -6 ... -11 % per batch: their launches do not
+        // fill the chip), one stream at B x U > 8192 units (measured +-0 at B = 64: power-limited, not tail-limited -- and
+        // per-kernel timings stay clean there).  PARROT_MRF_STREAMS=1 / 3 forces either.
+        const bool on = e ? atoi(e) > 1 : true;
+        v->mrf_auto = (e == nullptr);
         v->mrf_streams = (on && cfg->n_kernels > 1) ? cfg->n_kernels : 1;
         if (v->mrf_streams > 1) {
             for (int j = 1; j < v->mrf_streams; ++j) HIP_TRY(hipStreamCreateWithFlags(&v->side[j], hipStreamNonBlocking));
@@ -717,7 +725,12 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     //   16 channels: packed here for the 16x16x32 MFMA (step = tap pair; lane = row l&15, channels 8(g&1).., tap 2*step + (g>>1)).
     v->rb_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
     v->rb_wsc.assign((size_t)w->n_rb, 1.f);
+    v->rb_kind.assign((size_t)cfg->n_stages * cfg->n_kernels, 0);
+    v->rb_conv_halves.assign((size_t)cfg->n_stages * cfg->n_kernels, 0);
     const int NP = scheme_pieces(v->scheme);
+    // (resblock_split16_kernel: the pair kernel on 16x16x32 tiles -- half the LDS fragment bytes per MAC, but 208 VGPRs = two
+    //  workgroups per CU instead of three: 4.9 vs 4.7 ms per step, so it is opt-in)
+    static const bool rb16_on = [] { const char* e = getenv("PARROT_RB16"); return e && atoi(e) != 0; }();
     for (int i = 0; i < cfg->n_stages && v->scheme >= 1; ++i)
         for (int j = 0; j < cfg->n_kernels; ++j) {
             const int rk = cfg->resblock_kernel_sizes[j], C = v->chan(i);
@@ -725,7 +738,36 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
             const int base = (i * cfg->n_kernels + j) * per_rb;
             const int steps = resblock_split_steps(C, rk);
             const size_t step_b = (size_t)NP * 1024, conv_b = (size_t)steps * step_b;
-            if (C >= 32) {  // the plans' streams are already [row tile][chunk * k + tap]
+            v->rb_conv_halves[(size_t)i * cfg->n_kernels + j] = conv_b / 2;
+            if (C >= 32 && rb16_on && resblock_split16_has(v->scheme, C)) {
+                // 16x16x32 pair kernel: [conv][tap * (C/32) + chunk][row tile][piece][lane][8]; lane = row l & 15, channels 8 (l >> 4)..
+                const int CM = C / 16, NCH = C / 32, st16 = resblock_split16_steps(C, rk);
+                const size_t step_h = (size_t)CM * NP * 512, conv_h = (size_t)st16 * step_h;
+                std::vector<uint16_t> pk(((size_t)per_rb * st16 + 2) * step_h, 0);
+                for (int q = 0; q < per_rb; ++q) {
+                    const float* wq = w->rb_w[base + q];  // (C, C, rk)
+                    const float wsc = scheme_is_f16(v->scheme) ? f16_weight_scale(wq, (size_t)C * C * rk) : 1.f;
+                    v->rb_wsc[base + q] = wsc;
+                    for (int tap = 0; tap < rk; ++tap)
+                        for (int c32 = 0; c32 < NCH; ++c32)
+                            for (int tm = 0; tm < CM; ++tm) {
+                                uint16_t* g = pk.data() + (size_t)q * conv_h + ((size_t)tap * NCH + c32) * step_h + (size_t)tm * NP * 512;
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int e = 0; e < 8; ++e) {
+                                        const int row = 16 * tm + (lane & 15), ch = 32 * c32 + 8 * (lane >> 4) + e;
+                                        uint16_t h[3];
+                                        split_weight(wq[((size_t)row * C + ch) * rk + tap], v->scheme, wsc, h);
+                                        for (int pc = 0; pc < NP; ++pc) g[pc * 512 + lane * 8 + e] = h[pc];
+                                    }
+                            }
+                }
+                uint16_t* st = nullptr;
+                HIP_TRY(hipMalloc((void**)&st, pk.size() * sizeof(uint16_t)));
+                HIP_TRY(hipMemcpy(st, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                v->rb_stream[(size_t)i * cfg->n_kernels + j] = st;
+                v->rb_kind[(size_t)i * cfg->n_kernels + j] = 1;
+                v->rb_conv_halves[(size_t)i * cfg->n_kernels + j] = conv_h;
+            } else if (C >= 32) {  // the plans' streams are already [row tile][chunk * k + tap]
                 bool ok = true;
                 for (int q = 0; q < per_rb; ++q) {
                     const parrot_conv* pc = v->rb[base + q].get();
@@ -870,7 +912,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         ResblockSplitParams p{};
         p.x = src;
         p.y = last ? y : ((n_launch & 1) ? tmp_b : tmp_a);
-        p.wstream = stream + (size_t)m0 * steps * scheme_pieces(v->scheme) * 512;
+        p.wstream = stream + (size_t)m0 * v->rb_conv_halves[(size_t)stage * c.n_kernels + j];
         p.n_conv = m1 - m0;
         for (int q = m0; q < m1; ++q) {
             p.bias[q - m0] = v->rb[base + q]->bias;
@@ -893,8 +935,9 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         ProfRec rec{};
         const double macs = (double)B * C * C * k * T * (m1 - m0);
         if (last && before_last) HIP_TRY(hipStreamWaitEvent(s, before_last, 0));  // the MRF sum is accumulated in branch order
-        if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
-        HIP_TRY(launch_resblock_split(v->scheme, C, p, s));
+        const bool k16 = v->rb_kind[(size_t)stage * c.n_kernels + j] == 1;
+        if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : k16 ? 11 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
+        HIP_TRY(v->rb_kind[(size_t)stage * c.n_kernels + j] == 1 ? launch_resblock_split16(v->scheme, C, p, s) : launch_resblock_split(v->scheme, C, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
         src = p.y;
         m0 = m1;
@@ -933,11 +976,12 @@ extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, co
     Arena a(ws, ws_bytes);
     float* x0 = a.take<float>((size_t)B * c.model_in_dim * U);
     const size_t mx = voc_max_act(v, B, U);
-    const int ns = v->mrf_streams;
+    const int ns_alloc = v->mrf_streams;
+    const int ns = (v->mrf_auto && (long)B * U > 8192) ? 1 : v->mrf_streams;
     float* P[3];
     for (int i = 0; i < 3; ++i) P[i] = a.take<float>(mx);
     float* TMP[PARROT_MAX_KERNELS][3];  // (T1, RA, RB) per concurrent branch
-    for (int j = 0; j < ns; ++j)
+    for (int j = 0; j < ns_alloc; ++j)
         for (int q = 0; q < 3; ++q) TMP[j][q] = a.take<float>(mx);
     if (!a.ok) return fail(PARROT_E_NOMEM, "voc_forward: workspace too small");
 

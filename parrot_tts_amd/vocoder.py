@@ -8,6 +8,7 @@ parameters; all arithmetic runs in the HIP library (no torch compute, no CPU fal
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -26,6 +27,7 @@ class AttrDict(dict):
 
 
 MAX_WAV_VALUE = 32768.0  # reference utils/vocoder/dataset.py:22
+_CHECK_FINITE = os.environ.get("PARROT_CHECK_FINITE", "0") not in ("", "0")  # optional guard (costs a sync per forward)
 
 
 def get_padding(kernel_size: int, dilation: int = 1) -> int:
@@ -282,6 +284,10 @@ class CodeGenerator(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(lib.parrot_voc_forward_feats(self._handle, dptr(code), dptr(spkr), dptr(feats), n_feat, dptr(lens32), B, U,
                                                     dptr(wav), stage_ptrs, dptr(ws), ws.numel(), stream_ptr(dev)))
+        if _CHECK_FINITE and not bool(torch.isfinite(wav).all()):
+            # the default fp16x3 scheme needs |activation| < 8190 (include/parrot_hip.h): beyond that the output is inf/NaN
+            raise FloatingPointError("non-finite waveform: an activation left the fp16 split scheme's range; "
+                                     "use PARROT_PRECISION=bf16x6 (fp32's range) for this checkpoint")
         return wav
 
     # Receptive field of the whole generator, in units either side of an output frame (+-6378 output

@@ -1,0 +1,27 @@
+"""GPU: the library's runtime switches are read once per process, so each alternative code path is
+exercised in its own subprocess on a slice of the parity suite: full-size vocoder + TTE goldens and the ragged-row test."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SLICE = "voc_full_u40 or voc_small_resblock2 or tte_full_forced or ragged_batch_rows"
+
+SWITCHES = [
+    {"PARROT_MRF_STREAMS": "1"},                       # MRF branches on one stream (the small-batch default is three)
+    {"PARROT_MRF_STREAMS": "3", "PARROT_RB16": "1"},   # forced branch streams + the 16x16x32 fused pair kernel
+    {"PARROT_MFMA16": "0", "PARROT_FLASH_ATTN": "0"},  # 32x32x16 layer kernel everywhere, fp32-MFMA attention cores
+    {"PARROT_TTE_MERGE": "0", "PARROT_VALU_KERNELS": "0", "PARROT_STAGGER": "32"},
+]
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()))
+def test_parity_slice_under_switch(env):
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", SLICE,
+                          "-p", "no:cacheprovider"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, **env), timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
