@@ -168,14 +168,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
-    // XCD-aware block order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the M-blocks that read the
-    // SAME input slab are placed 8 ids apart -- same XCD, dispatched back to back: the second one finds the slab in L2
-    // instead of fetching it from HBM again.  id = ((tile / 8) * n_mblocks + mblock) * 8 + tile % 8.
+    // XCD-aware block order: workgroup ids go round-robin over the 8 XCDs (each with its own L2; tools/probes: id i runs on
+    // XCD i % 8).  Each XCD gets a CONTIGUOUS run of column tiles, walked in order with the M-blocks of a tile back to back:
+    // the M-blocks reading the same input slab and the neighbouring tiles re-reading its halo columns find them in that
+    // XCD's L2 instead of fetching them from HBM again.
     const int n_mb = (p.M + BM - 1) / BM;
-    const int grp8 = blockIdx.x / (8 * n_mb), within = blockIdx.x - grp8 * (8 * n_mb);
-    const int mblock = within >> 3;
-    const int tile_id = grp8 * 8 + (within & 7);
-    if (tile_id >= p.tiles_n * p.B) return;  // (grid padded up to a multiple of 8 tiles)
+    const int n_tiles = p.tiles_n * p.B, tpx = (n_tiles + 7) >> 3;  // column tiles per XCD
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;          // (workgroup id i runs on XCD i % 8, in id order)
+    const int mblock = seq % n_mb;
+    const int tile_id = xcd * tpx + seq / n_mb;
+    if (tile_id >= n_tiles || seq / n_mb >= tpx) return;
     const int b = tile_id / p.tiles_n;
     const int tn = tile_id - b * p.tiles_n;
     const int t0 = tn * BN;
@@ -476,7 +478,7 @@ inline void split_tile(int variant, int& bm, int& bn) {
     bm = (variant & 1) ? 64 : 128;
     bn = (variant & 1) ? 256 : 128;
 }
-inline unsigned split_grid(const ConvParams& p, int bm) {  // 1-D: (tiles rounded up to 8) x M-blocks, see the kernel's block order
+inline unsigned split_grid(const ConvParams& p, int bm) {  // 1-D: 8 XCDs x ceil(tiles / 8) x M-blocks, see the kernel's block order
     const unsigned tiles = (unsigned)p.tiles_n * p.B, n_mb = (p.M + bm - 1) / bm;
     return (tiles + 7) / 8 * 8 * n_mb;
 }

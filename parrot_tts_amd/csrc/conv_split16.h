@@ -41,12 +41,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void conv_split16_kernel(
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int g4 = lane >> 4, l15 = lane & 15;
 
-    // XCD-aware block order (see conv_split.h): the M-blocks of one column tile sit 8 workgroup ids apart
+    // XCD-aware block order (see conv_split.h): a contiguous run of column tiles per XCD, M-blocks back to back
     const int n_mb = (p.M + BM - 1) / BM;
-    const int grp8 = blockIdx.x / (8 * n_mb), within = blockIdx.x - grp8 * (8 * n_mb);
-    const int mblock = within >> 3;
-    const int tile_id = grp8 * 8 + (within & 7);
-    if (tile_id >= p.tiles_n * p.B) return;
+    const int n_tiles = p.tiles_n * p.B, tpx = (n_tiles + 7) >> 3;  // column tiles per XCD
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;          // (workgroup id i runs on XCD i % 8, in id order)
+    const int mblock = seq % n_mb;
+    const int tile_id = xcd * tpx + seq / n_mb;
+    if (tile_id >= n_tiles || seq / n_mb >= tpx) return;
     const int b = tile_id / p.tiles_n;
     const int tn0 = tile_id - b * p.tiles_n;
     const int t0 = tn0 * BN;
