@@ -27,7 +27,7 @@ struct BgemmParams {
     float alpha;
 };
 
-__global__ __launch_bounds__(256) void bgemm_mfma_kernel(const BgemmParams p) {
+static __global__ __launch_bounds__(256) void bgemm_mfma_kernel(const BgemmParams p) {
     constexpr int KC = 32, RS = 65;
     __shared__ float As[KC][RS];
     __shared__ float Bs[KC][RS];
@@ -446,19 +446,11 @@ inline hipError_t launch_attn_flash_t(const AttnParams& p, int B, hipStream_t s)
     hipLaunchKernelGGL(kern, dim3((p.T + 127) / 128, B * p.H), dim3(256), lds, s, p);
     return hipGetLastError();
 }
-inline hipError_t launch_attn_flash(const AttnParams& p, int B, hipStream_t s) {
-    switch (p.hd) {
-        case 128: return launch_attn_flash_t<128>(p, B, s);
-        case 64: return launch_attn_flash_t<64>(p, B, s);
-        case 32: return launch_attn_flash_t<32>(p, B, s);
-        case 16: return launch_attn_flash_t<16>(p, B, s);
-        default: return hipErrorInvalidValue;
-    }
-}
+hipError_t launch_attn_flash(const AttnParams& p, int B, hipStream_t s);  // csrc/tu_attn.hip
 
 // MFMA fragment-layout probe: D = A(32x2) * B(2x32) with A[i][k] = i + 100k, B[k][j] = (k ? 1000 : 1) * (j+1)
 // dumps the 16 accumulator registers of every lane so the host can check the assumed C/D mapping.
-__global__ void mfma_probe_kernel(float* out) {
+static __global__ void mfma_probe_kernel(float* out) {
     const int lane = threadIdx.x;
     const int i = lane & 31, k = lane >> 5;
     const float a = (float)(i + 100 * k);

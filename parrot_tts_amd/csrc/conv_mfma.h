@@ -76,7 +76,7 @@ struct ConvParams {
 // 64x into this epilogue costs ~40 VGPRs and a wave of occupancy.
 __device__ __forceinline__ float apply_act(float v, int act) { return (act == ACT_RELU && v < 0.f) ? 0.f : v; }
 
-__global__ void tanh_inplace_kernel(float* __restrict__ y, size_t n) {
+static __global__ void tanh_inplace_kernel(float* __restrict__ y, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = tanhf(y[i]);
 }

@@ -528,12 +528,17 @@ inline hipError_t launch_conv_split_generic(int variant, const ConvParams& p, hi
     if (variant & 1) return launch_conv_split_t<SCH, 1, 4, 2, 2, 2, 0>(p, grid, s);
     return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 0>(p, grid, s);
 }
+// Per-scheme entry points, each defined in its own translation unit (csrc/tu_*.hip) so the library builds in parallel.
+hipError_t launch_conv_split_f16x3(int variant, const ConvParams& p, hipStream_t s);
+hipError_t launch_conv_split_bf16x6(int variant, const ConvParams& p, hipStream_t s);
+hipError_t launch_conv_split_bf16(int variant, const ConvParams& p, hipStream_t s);
+hipError_t launch_conv_split_f16(int variant, const ConvParams& p, hipStream_t s);
 inline hipError_t launch_conv_split(int scheme, int variant, const ConvParams& p, hipStream_t s) {
     switch (scheme) {
-        case SchBf16x6::ID: return launch_conv_split_s<SchBf16x6>(variant, p, s);
-        case SchF16x3::ID: return launch_conv_split_s<SchF16x3>(variant, p, s);
-        case SchBf16::ID: return launch_conv_split_generic<SchBf16>(variant, p, s);
-        case SchF16::ID: return launch_conv_split_generic<SchF16>(variant, p, s);
+        case SchBf16x6::ID: return launch_conv_split_bf16x6(variant, p, s);
+        case SchF16x3::ID: return launch_conv_split_f16x3(variant, p, s);
+        case SchBf16::ID: return launch_conv_split_bf16(variant, p, s);
+        case SchF16::ID: return launch_conv_split_f16(variant, p, s);
         default: return hipErrorInvalidValue;
     }
 }

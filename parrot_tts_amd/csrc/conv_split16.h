@@ -281,8 +281,9 @@ inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStr
         default: return hipErrorInvalidValue;
     }
 }
+hipError_t launch_conv_split16_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16.hip
 inline hipError_t launch_conv_split16(int scheme, int variant, const ConvParams& p, hipStream_t s) {
-    if (scheme == SchF16x3::ID) return launch_conv_split16_s<SchF16x3>(variant, p, s);
+    if (scheme == SchF16x3::ID) return launch_conv_split16_f16x3(variant, p, s);
     return hipErrorInvalidValue;
 }
 

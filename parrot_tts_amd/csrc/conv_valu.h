@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void conv1_valu_kernel(const ConvValuParams p)
 // outputs are the three aligned quads at t0 - 4, t0, t0 + 4 -- 3 buffer_load_dwordx4 per channel instead of 10 strided
 // dword loads (the texture-address path, not HBM, bounded the dword version at 1.9 TB/s).  A quad is either inside
 // the row or entirely outside it (-> 0); only a ragged row end (Tlim % 4 != 0) needs per-sample masking.
-__global__ __launch_bounds__(256) void conv1_valu7_vec_kernel(const ConvValuParams p) {
+static __global__ __launch_bounds__(256) void conv1_valu7_vec_kernel(const ConvValuParams p) {
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;

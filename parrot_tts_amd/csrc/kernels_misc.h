@@ -12,7 +12,7 @@ namespace parrot {
 // grid (ceil(U/64), C/?, B): each block = 64 time steps x 64 channels via an LDS transpose so that
 // both the embedding-row reads (contiguous in c) and the (B,C,U) writes (contiguous in t) coalesce.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __restrict__ code, const int64_t* __restrict__ spkr,
+static __global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __restrict__ code, const int64_t* __restrict__ spkr,
                                                         const float* __restrict__ dict, const float* __restrict__ spk_tab,
                                                         float* __restrict__ x, int U, int E, int C, int Cx, int n_emb, int n_spk,
                                                         int* __restrict__ err) {  // C embedding channels of the Cx input channels
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __restric
 // ---------------------------------------------------------------------------------------------
 // TTE input: x[b, c, s] = tok_emb[phones[b,s]][c] + pe[S][c]   (parrot.py:94-95, fft.py:17-19, Q1)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tte_embed_kernel(const int64_t* __restrict__ phones, const float* __restrict__ emb,
+static __global__ __launch_bounds__(256) void tte_embed_kernel(const int64_t* __restrict__ phones, const float* __restrict__ emb,
                                                         const float* __restrict__ pe_row, float* __restrict__ x, int S, int D,
                                                         int vocab, int* __restrict__ err) {
     __shared__ float tile[64][65];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void tte_embed_kernel(const int64_t* __restric
 }
 
 // x[b, c, t] += tab[id[b]][c]      (speaker embedding add, parrot.py:98-99, Q6: all positions incl. pads)
-__global__ void add_channel_vec_kernel(float* __restrict__ x, const int64_t* __restrict__ id, const float* __restrict__ tab,
+static __global__ void add_channel_vec_kernel(float* __restrict__ x, const int64_t* __restrict__ id, const float* __restrict__ tab,
                                        int C, int T, int n_rows, size_t total, int* __restrict__ err) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -183,7 +183,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void softmax_mask_kernel(float* __restrict__ s, const uint8_t* __restrict__ key_valid, int rows,
+static __global__ __launch_bounds__(256) void softmax_mask_kernel(float* __restrict__ s, const uint8_t* __restrict__ key_valid, int rows,
                                                            int T, int HT) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void softmax_mask_kernel(float* __restrict__ s
 // dur = max(rint(exp(ld) - 1), 0) as int64 (torch.round = round-half-even = rintf);
 // one block per batch row also produces out_len[b] = sum(dur) and the exclusive prefix sums.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void duration_kernel(const float* __restrict__ ld_raw, const uint8_t* __restrict__ src_valid,
+static __global__ __launch_bounds__(256) void duration_kernel(const float* __restrict__ ld_raw, const uint8_t* __restrict__ src_valid,
                                                        float* __restrict__ log_dur, int64_t* __restrict__ dur,
                                                        int32_t* __restrict__ cum /* (B,S) inclusive */, int32_t* __restrict__ out_len,
                                                        int S) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void duration_kernel(const float* __restrict__
 }
 
 // inclusive prefix sums + totals of given durations (parrot_length_regulator: the standalone entry point)
-__global__ __launch_bounds__(256) void dur_prefix_kernel(const int64_t* __restrict__ dur, int32_t* __restrict__ cum, int32_t* __restrict__ out_len, int S) {
+static __global__ __launch_bounds__(256) void dur_prefix_kernel(const int64_t* __restrict__ dur, int32_t* __restrict__ cum, int32_t* __restrict__ out_len, int S) {
     __shared__ int32_t part[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int per = (S + 255) / 256;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void dur_prefix_kernel(const int64_t* __restri
 // tgt_mask[b,t] = t <= len_b (Q2).   grid (ceil(L/64), B).  idx is recomputed per (b,t) once and
 // reused over channels.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ enc, const int32_t* __restrict__ cum,
+static __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ enc, const int32_t* __restrict__ cum,
                                                               const int32_t* __restrict__ out_len, const float* __restrict__ pe_row,
                                                               float* __restrict__ y, uint8_t* __restrict__ tgt_mask, int S, int L, int D) {
     const int b = blockIdx.y;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
 
 // argmax over channels of (B, V, L) logits -> ids (B, L); first maximal index wins (torch.argmax).
 // Optionally also writes logits transposed to the reference's (B, L, V) layout for tests.
-__global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L) {
+static __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L) {
     // lane = time step; the four waves scan a quarter of the vocabulary each, then the first maximum wins
     // (strict > inside a range, lower range first on ties: torch.argmax's first-occurrence rule)
     __shared__ float bv[4][64];
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict_
 }
 
 // (B, C, T) -> (B, T, C) transpose (tests / optional logits export)
-__global__ __launch_bounds__(256) void transpose_cf_to_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T) {
+static __global__ __launch_bounds__(256) void transpose_cf_to_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T) {
     __shared__ float tile[64][65];
     const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -368,12 +368,12 @@ __global__ __launch_bounds__(256) void transpose_cf_to_cl_kernel(const float* __
 
 // wav fp32 -> int16 exactly like numpy's `(x * 32768).astype('int16')` for in-range values
 // (C cast: truncation toward zero; utils/vocoder/inference.py:71-73).
-__global__ void wav_to_int16_kernel(const float* __restrict__ w, int16_t* __restrict__ o, size_t n) {
+static __global__ void wav_to_int16_kernel(const float* __restrict__ w, int16_t* __restrict__ o, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = (int16_t)(int32_t)(w[i] * 32768.0f);
 }
 
-__global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) {
+static __global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) b[i] = a[i];
 }

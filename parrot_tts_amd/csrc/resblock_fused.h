@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 1) void resblock_fused_kernel(const ResblockPa
 // ---- 16-channel variant on v_mfma_f32_16x16x4_f32 (no zero-padded MFMA rows; see conv_mfma16.h for the fragment
 // layouts).  Window 1024 columns, 8 waves x 8 tiles of 16; LDS row stride 16 (mod 32) dwords.
 constexpr int RB16_PAD = 40;
-__global__ __launch_bounds__(512, 1) void resblock_fused16_kernel(const ResblockParams p) {
+static __global__ __launch_bounds__(512, 1) void resblock_fused16_kernel(const ResblockParams p) {
     constexpr int NT16 = 8;
     constexpr int W0 = 8 * NT16 * 16;      // 1024
     constexpr int RS = W0 + 2 * RB16_PAD;  // 1104 = 16 (mod 32)

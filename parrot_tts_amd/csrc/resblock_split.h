@@ -552,12 +552,16 @@ inline hipError_t launch_resblock_split_s(int C, const ResblockSplitParams& p, h
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
     return hipGetLastError();
 }
+hipError_t launch_resblock_split_f16x3(int C, const ResblockSplitParams& p, hipStream_t s);   // csrc/tu_resblock.hip
+hipError_t launch_resblock_split_bf16x6(int C, const ResblockSplitParams& p, hipStream_t s);  // csrc/tu_resblock.hip
+hipError_t launch_resblock_split_bf16(int C, const ResblockSplitParams& p, hipStream_t s);    // csrc/tu_split_single.hip
+hipError_t launch_resblock_split_f16(int C, const ResblockSplitParams& p, hipStream_t s);     // csrc/tu_split_single.hip
 inline hipError_t launch_resblock_split(int scheme, int C, const ResblockSplitParams& p, hipStream_t s) {
     switch (scheme) {
-        case SchBf16x6::ID: return launch_resblock_split_s<SchBf16x6>(C, p, s);
-        case SchF16x3::ID: return launch_resblock_split_s<SchF16x3>(C, p, s);
-        case SchBf16::ID: return launch_resblock_split_s<SchBf16>(C, p, s);
-        case SchF16::ID: return launch_resblock_split_s<SchF16>(C, p, s);
+        case SchBf16x6::ID: return launch_resblock_split_bf16x6(C, p, s);
+        case SchF16x3::ID: return launch_resblock_split_f16x3(C, p, s);
+        case SchBf16::ID: return launch_resblock_split_bf16(C, p, s);
+        case SchF16::ID: return launch_resblock_split_f16(C, p, s);
         default: return hipErrorInvalidValue;
     }
 }

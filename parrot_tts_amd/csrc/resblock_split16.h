@@ -265,8 +265,9 @@ inline hipError_t launch_resblock_split16_s(int C, const ResblockSplitParams& p,
     return hipGetLastError();
 }
 inline bool resblock_split16_has(int scheme, int C) { return scheme == SchF16x3::ID && (C == 32 || C == 64); }
+hipError_t launch_resblock_split16_f16x3(int C, const ResblockSplitParams& p, hipStream_t s);  // csrc/tu_split16.hip
 inline hipError_t launch_resblock_split16(int scheme, int C, const ResblockSplitParams& p, hipStream_t s) {
-    if (scheme == SchF16x3::ID) return launch_resblock_split16_s<SchF16x3>(C, p, s);
+    if (scheme == SchF16x3::ID) return launch_resblock_split16_f16x3(C, p, s);
     return hipErrorInvalidValue;
 }
 inline int resblock_split16_steps(int C, int k) { return k * (C / 32); }  // k-steps per conv; each CM * NP KiB
