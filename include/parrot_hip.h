@@ -163,6 +163,13 @@ int parrot_voc_forward(parrot_voc_t*, const int64_t* code, const int64_t* spkr, 
 int parrot_voc_forward_feats(parrot_voc_t*, const int64_t* code, const int64_t* spkr, const float* feats, int32_t n_feat_channels,
                              const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out, float* const* stage_out, void* ws,
                              size_t ws_bytes, void* stream);
+/* Chunk-streamed synthesis (long-form utterances, BASELINE configs[4]): chunks of `chunk_units` units are vocoded with
+ * `halo_units` units of real context on both sides (< 0: the generator's receptive field, 20 units = 6 400 samples) and only
+ * their own samples land in wav_out (B,1,U*hop): equal to parrot_voc_forward on the whole utterance to fp32 round-off, with
+ * the activation memory of chunk_units + 2*halo_units units.  Not for models with extra conditioning streams. */
+size_t parrot_voc_chunked_workspace_bytes(const parrot_voc_t*, int32_t B, int32_t chunk_units, int32_t halo_units);
+int parrot_voc_forward_chunked(parrot_voc_t*, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B, int32_t U,
+                               int32_t chunk_units, int32_t halo_units, float* wav_out, void* ws, size_t ws_bytes, void* stream);
 int parrot_voc_check(parrot_voc_t*, void* stream);
 /* wav (n) fp32 -> int16 as `(x*32768).astype('int16')` does (utils/vocoder/inference.py:71-73) */
 int parrot_wav_to_int16(const float* wav, int16_t* out, size_t n, void* stream);

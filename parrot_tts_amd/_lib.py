@@ -82,6 +82,8 @@ SIGNATURES = {
     "parrot_voc_workspace_bytes": (sz, [vp, i32, i32]),
     "parrot_voc_forward": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, C.POINTER(vp), vp, sz, vp]),
     "parrot_voc_forward_feats": (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, vp, C.POINTER(vp), vp, sz, vp]),
+    "parrot_voc_chunked_workspace_bytes": (sz, [vp, i32, i32, i32]),
+    "parrot_voc_forward_chunked": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "parrot_voc_check": (C.c_int, [vp, vp]),
     "parrot_wav_to_int16": (C.c_int, [vp, vp, sz, vp]),
     "parrot_tte_create": (C.c_int, [C.POINTER(vp), C.POINTER(TteCfg), C.POINTER(TteWeights)]),

@@ -15,7 +15,7 @@ namespace parrot {
 static __global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __restrict__ code, const int64_t* __restrict__ spkr,
                                                         const float* __restrict__ dict, const float* __restrict__ spk_tab,
                                                         float* __restrict__ x, int U, int E, int C, int Cx, int n_emb, int n_spk,
-                                                        int* __restrict__ err) {  // C embedding channels of the Cx input channels
+                                                        int* __restrict__ err, int code_stride) {  // C embedding channels of the Cx input channels; code rows code_stride apart
     __shared__ float tile[64][65];
     const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 rows of 64
@@ -25,7 +25,7 @@ static __global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __
         float v = 0.f;
         if (t < U && c < C) {
             if (c < E) {
-                int64_t id = code[(size_t)b * U + t];
+                int64_t id = code[(size_t)b * code_stride + t];
                 if (id < 0 || id >= n_emb) { atomicExch(err, 1); id = 0; }
                 v = dict[(size_t)id * E + c];
             } else {
@@ -247,6 +247,12 @@ static __global__ __launch_bounds__(256) void duration_kernel(const float* __res
         run += (int32_t)dur[(size_t)b * S + s];
         cum[(size_t)b * S + s] = run;
     }
+}
+
+// per-row unit counts re-based to a chunk [lo, lo + n): clamp(len - lo, 0, n)   (parrot_voc_forward_chunked)
+static __global__ void rebase_lens_kernel(const int32_t* __restrict__ lens, int32_t* __restrict__ out, int B, int lo, int n) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = min(max(lens[b] - lo, 0), n);
 }
 
 // inclusive prefix sums + totals of given durations (parrot_length_regulator: the standalone entry point)

@@ -955,14 +955,70 @@ extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, i
     return align_up(a.off, 256);
 }
 
+static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_stride, const int64_t* spkr, const float* feats,
+                            int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
+                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
                                   int32_t U, float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
-    return parrot_voc_forward_feats(v, code, spkr, nullptr, 0, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+    return voc_forward_impl(v, code, U, spkr, nullptr, 0, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
 }
 
 extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const float* feats,
                                         int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
                                         float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
+    return voc_forward_impl(v, code, U, spkr, feats, n_feat_channels, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+}
+
+// Chunk-streamed synthesis inside the library (`chunk_units`; BASELINE configs[4]): consecutive chunks of
+// `chunk_units` units are vocoded with `halo_units` (< 0: the generator's receptive field, 20) of real context on both
+// sides and only their own samples are copied into wav_out -- equal to the whole-utterance forward to fp32 round-off,
+// with the activation memory of chunk_units + 2 halo_units units.  Chunks that touch a true sequence edge contain the edge.
+static const int VOC_RECEPTIVE_UNITS = 20;
+extern "C" size_t parrot_voc_chunked_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t chunk_units, int32_t halo_units) {
+    if (!v || B <= 0 || chunk_units <= 0) return 0;
+    const int halo = halo_units < 0 ? VOC_RECEPTIVE_UNITS : halo_units;
+    const int span = chunk_units + 2 * halo;
+    Arena a(nullptr, 0);
+    a.take<float>((size_t)B * span * v->up_total);
+    a.take<int32_t>((size_t)B);
+    a.off = align_up(a.off, 256) + parrot_voc_workspace_bytes(v, B, span);
+    return align_up(a.off, 256);
+}
+extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
+                                          int32_t U, int32_t chunk_units, int32_t halo_units, float* wav_out, void* ws, size_t ws_bytes,
+                                          void* stream) {
+    if (!v || !code || !wav_out || !ws) return fail(PARROT_E_INVALID, "voc_forward_chunked: null argument");
+    if (B <= 0 || U <= 0 || chunk_units <= 0) return fail(PARROT_E_INVALID, "voc_forward_chunked: empty batch or chunk");
+    if (v->cfg.model_in_dim != v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1))
+        return fail(PARROT_E_UNSUPPORTED, "voc_forward_chunked: models with extra conditioning streams go through parrot_voc_forward_feats");
+    const int halo = halo_units < 0 ? VOC_RECEPTIVE_UNITS : halo_units;
+    const int span = chunk_units + 2 * halo, hop = v->up_total;
+    hipStream_t s = (hipStream_t)stream;
+    Arena a(ws, ws_bytes);
+    float* tmp = a.take<float>((size_t)B * span * hop);
+    int32_t* lens = a.take<int32_t>((size_t)B);
+    a.off = align_up(a.off, 256);
+    const size_t inner = parrot_voc_workspace_bytes(v, B, span);
+    if (!a.ok || a.off + inner > ws_bytes) return fail(PARROT_E_NOMEM, "voc_forward_chunked: workspace too small");
+    void* inner_ws = (char*)ws + a.off;
+    for (int start = 0; start < U; start += chunk_units) {
+        const int stop = std::min(U, start + chunk_units);
+        const int lo = std::max(0, start - halo), hi = std::min(U, stop + halo), n = hi - lo;
+        if (unit_lens) {
+            hipLaunchKernelGGL(rebase_lens_kernel, dim3((B + 255) / 256), dim3(256), 0, s, unit_lens, lens, B, lo, n);
+            HIP_TRY(hipGetLastError());
+        }
+        TRY(voc_forward_impl(v, code + lo, U, spkr, nullptr, 0, unit_lens ? lens : nullptr, B, n, tmp, nullptr, inner_ws, inner, stream));
+        HIP_TRY(hipMemcpy2DAsync(wav_out + (size_t)start * hop, (size_t)U * hop * sizeof(float), tmp + (size_t)(start - lo) * hop,
+                                 (size_t)n * hop * sizeof(float), (size_t)(stop - start) * hop * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+    }
+    return PARROT_OK;
+}
+
+static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_stride, const int64_t* spkr, const float* feats,
+                            int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
+                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
     if (!v || !code || !wav_out || !ws) return fail(PARROT_E_INVALID, "voc_forward: null argument");
     {
         const int base = v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1);
@@ -989,7 +1045,7 @@ extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, co
         const int base = c.embedding_dim * (c.multispkr ? 2 : 1);
         dim3 grid((U + 63) / 64, (base + 63) / 64, B);
         hipLaunchKernelGGL(voc_embed_kernel, grid, dim3(256), 0, s, code, spkr, v->dict, v->spkr, x0, U, c.embedding_dim,
-                           base, c.model_in_dim, c.num_embeddings, c.n_spkr, v->err);
+                           base, c.model_in_dim, c.num_embeddings, c.n_spkr, v->err, code_stride);
         HIP_TRY(hipGetLastError());
         if (n_feat_channels > 0)  // extra conditioning streams (already upsampled to U frames) behind the embeddings
             HIP_TRY(hipMemcpy2DAsync(x0 + (size_t)base * U, (size_t)c.model_in_dim * U * sizeof(float), feats,

@@ -321,8 +321,28 @@ class CodeGenerator(nn.Module):
     @torch.no_grad()
     def forward_chunked(self, chunk_units: int = 256, halo_units: Optional[int] = None, unit_lens: Optional[torch.Tensor] = None,
                         **kwargs) -> torch.Tensor:
-        """``forward`` assembled from ``stream`` chunks: same result, bounded activation memory."""
+        """``forward`` in chunks: same result, bounded activation memory.  Without extra conditioning keywords the chunk loop
+        runs inside the library (``parrot_voc_forward_chunked``); otherwise it is assembled from ``stream`` chunks."""
         code = kwargs["code"]
+        if not [k for k in kwargs if k not in ("code", "spkr", "f0")] and self._in_dim == self._emb_dim * (2 if self.multispkr else 1):
+            require_cuda(code, "code")
+            dev = code.device
+            self._current_handle(dev)
+            code = code.contiguous()
+            B, U = code.shape
+            spkr = kwargs["spkr"].to(dev).reshape(-1).contiguous() if self.multispkr else None
+            lens32 = None if unit_lens is None else unit_lens.to(dev, torch.int32).contiguous()
+            halo = -1 if halo_units is None else int(halo_units)
+            lib = _lib.lib()
+            key = ("chunked", B, int(chunk_units), halo)
+            if key not in self._ws:
+                self._ws = {key: torch.empty(lib.parrot_voc_chunked_workspace_bytes(self._handle, B, int(chunk_units), halo), dtype=torch.uint8, device=dev)}
+            ws = self._ws[key]
+            wav = torch.empty((B, 1, U * self.upsample_factor), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.parrot_voc_forward_chunked(self._handle, dptr(code), dptr(spkr), dptr(lens32), B, U, int(chunk_units), halo,
+                                                          dptr(wav), dptr(ws), ws.numel(), stream_ptr(dev)))
+            return wav
         out = torch.empty((code.shape[0], 1, code.shape[1] * self.upsample_factor), dtype=torch.float32, device=code.device)
         for first, wav in self.stream(chunk_units, halo_units, unit_lens=unit_lens, **kwargs):
             out[:, :, first:first + wav.shape[-1]] = wav
