@@ -28,6 +28,7 @@
 //     re-fetched in place for step + 2 right after its last use, in the generic kernel one step ahead.
 //   * accumulator init / epilogue are shared with the exact kernel (same 32x32 C/D layout).
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_mfma.h"
@@ -144,12 +145,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 // otherwise pays one barrier, one conversion pass over tile + 64 halo columns and one pipeline bubble per MFMA step.
 template <class SCH, int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel(const ConvParams p) {
-    static_assert(SUBS == 1 || K == 1, "sub-slab staging is for 1x1 convs");
+    static_assert(SUBS == 1 || K == 1 || K == 3, "sub-slab staging: 1x1 convs (no halo) and k = 3 (two 16-channel slabs per barrier)");
     constexpr int NPC = SCH::NP, NTERM = SCH::NT;
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
-    constexpr int COLS = BN + (SUBS > 1 ? 0 : CONV_HALO);  // staged columns per chunk
+    constexpr int COLS = BN + ((SUBS > 1 && K == 1) ? 0 : CONV_HALO);  // staged columns per chunk
     constexpr int PIECE_BYTES = COLS * 32;         // [col][16 ch] 16-bit
     constexpr int SUB_BYTES = NPC * PIECE_BYTES;   // one 16-channel sub-slab
     constexpr int BUF_BYTES = SUBS * SUB_BYTES;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
 template <class SCH, int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1>
 inline hipError_t launch_conv_split_t(const ConvParams& p, dim3 grid, hipStream_t s) {
     constexpr int BN = WAVES_N * WN * 32;
-    const size_t lds = (size_t)2 * SUBS * SCH::NP * (BN + (SUBS > 1 ? 0 : CONV_HALO)) * 32;
+    const size_t lds = (size_t)2 * SUBS * SCH::NP * (BN + ((SUBS > 1 && K == 1) ? 0 : CONV_HALO)) * 32;
     auto kern = conv_split_kernel<SCH, WAVES_M, WAVES_N, WM, WN, MINW, K, SUBS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -482,6 +483,11 @@ inline unsigned split_grid(const ConvParams& p, int bm) {  // 1-D: 8 XCDs x ceil
     const unsigned tiles = (unsigned)p.tiles_n * p.B, n_mb = (p.M + bm - 1) / bm;
     return (tiles + 7) / 8 * 8 * n_mb;
 }
+inline bool split_k3_subs2() {
+    // (measured +-0: the k = 3 layers of stages 0-1 move 2-3 TB/s of algorithmic bytes -- they are HBM-bound, not barrier-bound)
+    static const bool on = [] { const char* e = getenv("PARROT_K3_SUBS"); return e && atoi(e) != 0; }();
+    return on;
+}
 // the (tile, tap count) pairs of the synthesis path get the straight-line kernel, anything else the generic one
 template <class SCH>
 inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStream_t s) {
@@ -506,7 +512,9 @@ inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStrea
             default: return launch_conv_split_t<SCH, 1, 4, 2, 2, 2, 0>(p, grid, s);
         }
     switch (p.k) {
-        case 3: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3>(p, grid, s);
+        case 3:
+            if (split_k3_subs2() && p.nchunks % 2 == 0 && SCH::NP <= 2) return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3, 2>(p, grid, s);  // 32 channels per barrier
+            return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3>(p, grid, s);
         case 7: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 7>(p, grid, s);
         case 9: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 9>(p, grid, s);
         case 11: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 11>(p, grid, s);
