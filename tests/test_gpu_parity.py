@@ -243,8 +243,16 @@ VOC_GOLDENS = ["voc_small", "voc_small_singlespk", "voc_small_resblock2", "voc_f
                "voc_full_u256"]
 
 
+def _skip_duplicate_mode(prec, fused):
+    """Fused modes 1 and 2 differ only in the exact-fp32 32-channel whole-block kernel: under the split schemes they run
+    the same kernels, so that third of the matrix would be duplicate work."""
+    if fused == 1 and prec != "f32":
+        pytest.skip("fused modes 1 and 2 are the same kernels under the split schemes")
+
+
 @pytest.mark.parametrize("name", VOC_GOLDENS)
 def test_vocoder_matches_reference_golden(golden_dir, name, prec, fused):
+    _skip_duplicate_mode(prec, fused)
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     m = json.loads(str(z["meta"]))
     h = _voc_cfg(name)
@@ -275,6 +283,7 @@ def test_vocoder_matches_reference_golden(golden_dir, name, prec, fused):
 
 
 def test_vocoder_matches_oracle_ragged_shapes(prec, fused):
+    _skip_duplicate_mode(prec, fused)
     h = synth.small_voc_config()
     sd = synth.synth_voc_state_dict(h, seed=21, scale=1.0)
     g = _gen(h, sd)
@@ -496,6 +505,7 @@ def test_long_form_and_odd_lengths(tmp_path):
 def test_vocoder_ragged_batch_rows_equal_single_utterance_runs(cfg_name, prec, fused):
     """A padded (ragged) batch with per-row unit counts: every row must equal the reference's own run of that utterance
     ALONE (the reference vocoder driver is B=1), although the rows are padded with arbitrary codes."""
+    _skip_duplicate_mode(prec, fused)
     h = synth.small_voc_config() if cfg_name == "small" else synth.default_voc_config()
     vsd = synth.synth_voc_state_dict(h, seed=31)
     gen = _gen(h, vsd)
