@@ -38,6 +38,7 @@ enum {
     PARROT_E_HIP = -3,         /* a HIP runtime call failed                                    */
     PARROT_E_NOMEM = -4,       /* workspace too small / allocation failed                      */
     PARROT_E_UNSUPPORTED = -5, /* configuration outside what the kernels cover                 */
+    PARROT_E_NONFINITE = -6,   /* parrot_voc_check: a waveform sample was NaN / inf (fp16 split range exceeded) */
 };
 
 int parrot_abi_version(void);
@@ -170,6 +171,9 @@ int parrot_voc_forward_feats(parrot_voc_t*, const int64_t* code, const int64_t* 
 size_t parrot_voc_chunked_workspace_bytes(const parrot_voc_t*, int32_t B, int32_t chunk_units, int32_t halo_units);
 int parrot_voc_forward_chunked(parrot_voc_t*, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B, int32_t U,
                                int32_t chunk_units, int32_t halo_units, float* wav_out, void* ws, size_t ws_bytes, void* stream);
+/* Synchronises `stream` and reports what the device flagged since the last check: PARROT_E_RANGE for a unit / speaker id
+ * outside the embedding tables (the reference's IndexError), PARROT_E_NONFINITE when a waveform sample left [-1, 1] as NaN /
+ * inf (an activation beyond the fp16 split scheme's range: never a silently wrong finite value). */
 int parrot_voc_check(parrot_voc_t*, void* stream);
 /* wav (n) fp32 -> int16 as `(x*32768).astype('int16')` does (utils/vocoder/inference.py:71-73) */
 int parrot_wav_to_int16(const float* wav, int16_t* out, size_t n, void* stream);

@@ -76,9 +76,13 @@ struct ConvParams {
 // 64x into this epilogue costs ~40 VGPRs and a wave of occupancy.
 __device__ __forceinline__ float apply_act(float v, int act) { return (act == ACT_RELU && v < 0.f) ? 0.f : v; }
 
-static __global__ void tanh_inplace_kernel(float* __restrict__ y, size_t n) {
+static __global__ void tanh_inplace_kernel(float* __restrict__ y, size_t n, int* __restrict__ err) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = tanhf(y[i]);
+    if (i < n) {
+        const float r = tanhf(y[i]);
+        y[i] = r;
+        if (err && !(fabsf(r) <= 1.0f)) atomicExch(err, 5);  // NaN / inf reached the waveform (fp16 split range exceeded)
+    }
 }
 
 // ---- shared by every conv kernel variant: accumulator init (bias + folded residual) and epilogue --------------

@@ -156,6 +156,7 @@ struct parrot_conv {
     int n_it16 = 0;
     float wscale = 1.f;        // power-of-two weight scale inside the fp16 pieces (1 for bf16 schemes)
     bool mfma16 = false;       // split plan packed for conv_split16_kernel (16x16x32 MFMA, 32-channel chunks)
+    int* err_flag = nullptr;   // device flag of the owning model (set on a non-finite tanh output: conv_post)
     bool late_res = false;     // add the residual in the epilogue instead of folding it into the accumulator init (TTE layers)
     int valu_kind = 0;         // 1: conv1_valu_kernel<7>, 2: convt_valu_kernel<16,4,2,1> (conv_valu.h); weights in their original layout
     float* wraw = nullptr;
@@ -485,6 +486,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         q.slope = c->d.pre_act == PRE_LRELU ? c->d.pre_slope : 1.f;
         q.act = c->d.act;
         q.row_len = row_len; q.row_len_mul = row_len_mul;
+        q.err = c->err_flag;
         ProfRec rec{};
         const double macs = (double)B * c->d.c_out * c->d.c_in * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 6 + c->valu_kind, 2.0 * macs, 4.0 * B * ((double)c->d.c_in * Tin + (double)c->d.c_out * Tout), s));
@@ -548,7 +550,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     HIP_TRY(c->mfma16 ? launch_conv_split16(c->prec, variant16, p, s) : c->prec >= 1 ? launch_conv_split(c->prec, variant16, p, s) : (cfg == 6 ? launch_conv_mfma16(p, s) : launch_conv(cfg, p, s)));
     if (c->d.act == ACT_TANH) {  // dense (B, Cout, Tout) output assumed for the tanh layers (conv_post)
         const size_t n = (size_t)B * c->Cout * Tout;
-        hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n);
+        hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n, c->err_flag);
         HIP_TRY(hipGetLastError());
     }
     if (g_prof_on) TRY(prof_close(rec, s));
@@ -810,6 +812,7 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
         }
     // final F.leaky_relu(x) uses the DEFAULT slope 0.01 (models.py:107, quirk Q5)
     TRY(make_conv(v->conv_post, C0 >> cfg->n_stages, 1, 7, 1, 3, 0, 1, PRE_LRELU, 0.01f, ACT_TANH, w->conv_post_w, w->conv_post_b));
+    v->conv_post->err_flag = v->err;  // a non-finite waveform sample (an activation left the fp16 split range) raises the handle's flag
     *out = v.release();
     return PARROT_OK;
 }
@@ -1529,6 +1532,9 @@ static int read_flag(int* err, hipStream_t s, const char* who) {
     HIP_TRY(hipStreamSynchronize(s));
     if (h) {
         HIP_TRY(hipMemsetAsync(err, 0, sizeof(int), s));
+        if (h == 5)
+            return fail(PARROT_E_NONFINITE, std::string(who) + ": non-finite waveform sample -- an activation left the range of the fp16 split "
+                                                                "scheme (|x| < 8190); create the handle with PARROT_PREC_BF16X6 or PARROT_PREC_F32");
         return fail(PARROT_E_RANGE, std::string(who) + ": embedding index out of range (code " + std::to_string(h) + ")");
     }
     return PARROT_OK;

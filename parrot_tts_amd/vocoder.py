@@ -366,14 +366,17 @@ class CodeGenerator(nn.Module):
         return signal.repeat_interleave(rep, dim=2)
 
     def check_inputs(self) -> None:
-        """Synchronise and raise IndexError if a unit / speaker id of an earlier forward was out of range
-        (what nn.Embedding raises eagerly in the reference)."""
+        """Synchronise and raise IndexError if a unit / speaker id of an earlier forward was out of range (what nn.Embedding
+        raises eagerly in the reference), FloatingPointError if a waveform sample came out non-finite (an activation beyond
+        the fp16 split scheme's range: use PARROT_PRECISION=bf16x6 for such a checkpoint)."""
         if self._handle is not None:
             try:
                 _lib.check(_lib.lib().parrot_voc_check(self._handle, stream_ptr(self._handle_device)))
             except _lib.ParrotHipError as e:
                 if e.code == -2:
                     raise IndexError(str(e)) from None
+                if e.code == -6:
+                    raise FloatingPointError(str(e)) from None
                 raise
 
 

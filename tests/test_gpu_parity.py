@@ -301,6 +301,29 @@ def test_vocoder_matches_oracle_ragged_shapes(prec, fused):
     assert torch.equal(yb[2:3], y1)
 
 
+def test_vocoder_flags_a_non_finite_waveform():
+    """fp16x3 needs |activation| < 8190: a checkpoint that blows through it must not produce silently wrong audio -- the
+    waveform goes non-finite and check_inputs() raises; the bf16x6 mode (fp32's range) synthesises the same model fine."""
+    h = synth.small_voc_config()
+    sd = synth.synth_voc_state_dict(h, seed=3)
+    sd["conv_pre.bias"] = sd["conv_pre.bias"] + 3.0e4     # drives the first activations far beyond the fp16 range
+    code = torch.zeros(1, 8, dtype=torch.int64, device=DEV)
+    spk = torch.zeros(1, 1, dtype=torch.int64, device=DEV)
+    g = _gen(h, sd)
+    y = g(code=code, spkr=spk)
+    assert not bool(torch.isfinite(y).all())
+    with pytest.raises(FloatingPointError):
+        g.check_inputs()
+    ops.set_default_precision(ops.PREC_BF16X6)
+    try:
+        g2 = _gen(h, sd)
+        y2 = g2(code=code, spkr=spk)
+        g2.check_inputs()
+        assert bool(torch.isfinite(y2).all())
+    finally:
+        ops.set_default_precision(ops.PREC_DEFAULT)
+
+
 def test_vocoder_rejects_bad_ids_and_cpu_tensors():
     h = synth.small_voc_config()
     g = _gen(h, synth.synth_voc_state_dict(h, seed=1))
