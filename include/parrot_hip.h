@@ -227,8 +227,9 @@ int parrot_tte_encode(parrot_tte_t*, const int64_t* phones, const uint8_t* src_m
 int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L,
                       int64_t* ids, uint8_t* tgt_mask, float* logits /* nullable */,
                       void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
-/* Device-side id-range flag (a bad phone / unit / speaker id <-> the reference's Embedding
- * IndexError).  Synchronises `stream`; returns 0 or PARROT_E_RANGE and clears the flag.       */
+/* Device-side flags.  Synchronises `stream`, clears the flag; returns 0, PARROT_E_RANGE (a bad phone / speaker id <-> the
+ * reference's Embedding IndexError) or PARROT_E_NONFINITE (NaN / inf logits at some position of the last decode: an
+ * activation beyond the fp16 split scheme's range -- the ids of that call are not to be trusted). */
 int parrot_tte_check(parrot_tte_t*, void* stream);
 /* Tests / error localisation: while set, the next encode / decode calls copy the channel-first (B, D, T) activation
  * after each stage to the given DEVICE buffers (NULL entries are skipped): enc_ptrs[0] = embedding + pe[S],

@@ -317,7 +317,8 @@ static __global__ __launch_bounds__(256) void length_regulate_kernel(const float
 
 // argmax over channels of (B, V, L) logits -> ids (B, L); first maximal index wins (torch.argmax).
 // Optionally also writes logits transposed to the reference's (B, L, V) layout for tests.
-static __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L) {
+static __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L,
+                                                               int* __restrict__ err) {
     // lane = time step; the four waves scan a quarter of the vocabulary each, then the first maximum wins
     // (strict > inside a range, lower range first on ties: torch.argmax's first-occurrence rule)
     __shared__ float bv[4][64];
@@ -353,6 +354,7 @@ static __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __re
         for (int w = 1; w < 4; ++w)
             if (bv[w][lane] > m) { m = bv[w][lane]; mi = bix[w][lane]; }
         ids[(size_t)b * L + t] = mi;
+        if (err && !(fabsf(m) < INFINITY)) atomicExch(err, 5);  // NaN / inf logits (an activation left the fp16 split range)
     }
 }
 

@@ -1463,7 +1463,7 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
         TRY(dbg(1 + n, w.x, (size_t)B * D * L));
     }
     TRY(conv_launch(t->head.get(), w.x, nullptr, w.logits, B, L, EPI_STORE, 1.f, 0, 0, 0, s));
-    hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, w.logits, ids, V, L);
+    hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, w.logits, ids, V, L, t->err);
     HIP_TRY(hipGetLastError());
     if (logits) {
         hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((L + 63) / 64, (V + 63) / 64, B), dim3(256), 0, s, w.logits, logits, V, L);
@@ -1533,7 +1533,7 @@ static int read_flag(int* err, hipStream_t s, const char* who) {
     if (h) {
         HIP_TRY(hipMemsetAsync(err, 0, sizeof(int), s));
         if (h == 5)
-            return fail(PARROT_E_NONFINITE, std::string(who) + ": non-finite waveform sample -- an activation left the range of the fp16 split "
+            return fail(PARROT_E_NONFINITE, std::string(who) + ": non-finite output (waveform sample / logits) -- an activation left the range of the fp16 split "
                                                                 "scheme (|x| < 8190); create the handle with PARROT_PREC_BF16X6 or PARROT_PREC_F32");
         return fail(PARROT_E_RANGE, std::string(who) + ": embedding index out of range (code " + std::to_string(h) + ")");
     }

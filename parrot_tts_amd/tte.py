@@ -204,6 +204,8 @@ class Parrot(nn.Module):
             except _lib.ParrotHipError as e:
                 if e.code == -2:  # PARROT_E_RANGE <-> the reference's IndexError (pe[T], Embedding)
                     raise IndexError(str(e)) from None
+                if e.code == -6:  # PARROT_E_NONFINITE (flag raised by an earlier decode)
+                    raise FloatingPointError(str(e)) from None
                 raise
         return {"ids": ids, "tgt_mask": tgt.bool(), "log_dur": log_dur, "dur": dur, "lens": lens_h, "logits": logits,
                 "src_mask": src_mask}
@@ -238,6 +240,19 @@ class Parrot(nn.Module):
         r["stages"] = st
         return r
 
+    def check_outputs(self) -> None:
+        """Synchronise and raise FloatingPointError if the last decode produced NaN / inf logits (an activation beyond the
+        fp16 split scheme's range; use PARROT_PRECISION=bf16x6 for such a checkpoint), IndexError for a bad id."""
+        if self._handle is not None:
+            try:
+                _lib.check(_lib.lib().parrot_tte_check(self._handle, stream_ptr(self._handle_device)))
+            except _lib.ParrotHipError as e:
+                if e.code == -2:
+                    raise IndexError(str(e)) from None
+                if e.code == -6:
+                    raise FloatingPointError(str(e)) from None
+                raise
+
     def forward(self, batch, inference=False):
         if inference is not True:
             raise NotImplementedError("parrot_tts_amd.Parrot implements the inference path only (training is out of scope)")
@@ -247,6 +262,7 @@ class Parrot(nn.Module):
     def infer(self, batch) -> List[List[int]]:
         assert self.training == False  # noqa: E712  (reference modules/parrot.py:113)
         r = self._run(batch, want_logits=False)
+        self.check_outputs()  # (infer() synchronises anyway to hand python lists back)
         ids, msk = r["ids"].cpu(), r["tgt_mask"].cpu()
         return [c[m].numpy().tolist() for c, m in zip(ids, msk)]
 

@@ -429,6 +429,23 @@ def test_tte_matches_oracle_other_shapes(tmp_path, prec):
         assert model.infer(gb) == ref_ids
 
 
+def test_tte_flags_non_finite_logits(tmp_path):
+    """An activation beyond the fp16 split range must not turn into silently wrong unit ids: infer() raises."""
+    cfg = synth.small_tte_config()
+    sd = synth.synth_tte_state_dict(cfg, 30, 1, seed=2, forced_duration=2)
+    sd["decoder_layers.0.convlayer.conv1.bias"] = sd["decoder_layers.0.convlayer.conv1.bias"] + 5.0e4
+    model = _parrot(cfg, 30, 1, sd, tmp_path)
+    batch = {k: v.to(DEV) for k, v in synth.synth_tte_batch(2, 9, 30, 1, seed=1).items()}
+    with pytest.raises(FloatingPointError):
+        model.infer(batch)
+    ops.set_default_precision(ops.PREC_BF16X6)
+    try:
+        m2 = _parrot(cfg, 30, 1, sd, tmp_path)
+        assert len(m2.infer(batch)) == 2
+    finally:
+        ops.set_default_precision(ops.PREC_DEFAULT)
+
+
 def test_tte_error_behaviour(tmp_path):
     cfg = synth.small_tte_config()
     sd = synth.synth_tte_state_dict(cfg, 30, 1, seed=0)
