@@ -617,6 +617,7 @@ struct parrot_voc {
     // launch tails, prologues and epilogues then overlap another branch's main loops.
     int mrf_streams = 1;
     bool mrf_auto = true;
+    std::mutex side_mu;  // the side streams / events are the handle's: concurrent callers enqueue their fork-join sequences one at a time
     hipStream_t side[PARROT_MAX_KERNELS] = {};
     hipEvent_t ev_fork = nullptr, ev_last[PARROT_MAX_KERNELS] = {};
     ~parrot_voc() {
@@ -1037,6 +1038,8 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
     const size_t mx = voc_max_act(v, B, U);
     const int ns_alloc = v->mrf_streams;
     const int ns = (v->mrf_auto && (long)B * U > 8192) ? 1 : v->mrf_streams;
+    std::unique_lock<std::mutex> side_lock(v->side_mu, std::defer_lock);
+    if (ns > 1) side_lock.lock();
     float* P[3];
     for (int i = 0; i < 3; ++i) P[i] = a.take<float>(mx);
     float* TMP[PARROT_MAX_KERNELS][3];  // (T1, RA, RB) per concurrent branch
