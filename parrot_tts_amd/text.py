@@ -4,8 +4,9 @@ TTE's `phones` batch, and the end-to-end text -> waveform helper of demo.ipynb.
 Host-side string work only.  The cleaner for non-transliterated Indic text is a restatement of the reference's
 dependency-free pipeline (utils/aligner/cleaners.py:204-233 with :169-202) and is pinned by golden vectors produced by
 the reference's own functions (tools/make_text_goldens.py -> tests/golden/text_cleaners.json).  The English and the
-transliterating pipelines of the reference need `unidecode` and `inflect`, which this image does not have: they are
-provided only when those packages are importable and are NOT pinned here (stated, not silently approximated)."""
+transliterating pipelines of the reference use `unidecode` and `inflect`, which this image does not have: they are
+restated and pinned for the part of the input space where neither package can matter (ASCII text; digit-free for the
+English one), use the packages when importable beyond that, and raise instead of approximating otherwise."""
 from __future__ import annotations
 
 import re
@@ -65,19 +66,115 @@ def indic_cleaners(text: str) -> str:
     return " ".join(text.split())
 
 
-def ascii_cleaners(text: str, english: bool) -> str:
-    """The reference's `english_cleaners` / `nonenglish_cleaners` (cleaners.py:120-167) transliterate with `unidecode` and
-    (English) spell numbers with `inflect`.  Neither package ships with this image, so this path is gated on them and
-    is not covered by golden vectors."""
+# ---- English / transliterating pipelines (cleaners.py:46-166) ---------------------------------------------------------
+# The reference transliterates with `unidecode` and spells numbers with `inflect`; neither ships with this image.  Both
+# are only NEEDED for part of the input space: `unidecode` passes ASCII through unchanged (its documented contract), and
+# every number rule of `normalize_numbers` starts from a digit.  So ASCII text is handled here without either package
+# (pinned by goldens the reference's own functions produced on such inputs, tools/make_text_goldens.py), and anything
+# beyond that uses the packages when they are importable and raises -- never approximates -- when they are not.
+_ABBREVIATIONS = [(re.compile("\\b%s\\." % a, re.IGNORECASE), b) for a, b in [
+    ("mrs", "misess"), ("&", "and"), ("mr", "mister"), ("dr", "doctor"), ("st", "saint"), ("co", "company"), ("jr", "junior"),
+    ("maj", "major"), ("gen", "general"), ("drs", "doctors"), ("rev", "reverend"), ("lt", "lieutenant"), ("hon", "honorable"),
+    ("sgt", "sergeant"), ("capt", "captain"), ("esq", "esquire"), ("ltd", "limited"), ("col", "colonel"), ("ft", "fort"),
+    ("tts", "text to speech")]]  # cleaners.py:16-37, in the reference's order (so "mrs." is taken before "mr.")
+_ENGLISH_DROP = ["#", "+", "\\", "_", "`", "@", "/", "-", "'", ">", "<", "(", ")", "*", '"', ":", ";", "!"]            # cleaners.py:129
+_NONENGLISH_DROP = ["|", "%", "+", "=", "[", "]", "^", "\\", "{", "}", "_", "`", "‘", "’", "@", "/", "-", "'", ">", "<", "(", ")",
+                    "*", '"', ":", ";", "!"]                                                                            # cleaners.py:153
+_NON_PRINTABLE = re.compile(r"[^\x20-\x7E]")
+_HAS_DIGIT = re.compile(r"[0-9]")
+
+
+def expand_abbreviations(text: str) -> str:
+    """cleaners.py:46-49"""
+    for rx, rep in _ABBREVIATIONS:
+        text = rx.sub(rep, text)
+    return text
+
+
+def _to_ascii(text: str) -> str:
+    """`unidecode(text)` (cleaners.py:122,144): the identity on ASCII input; anything else needs the package."""
+    if text.isascii():
+        return text
     try:
-        from unidecode import unidecode  # noqa: F401
-        if english:
-            import inflect  # noqa: F401
-    except ImportError as e:  # pragma: no cover - depends on the deployment image
-        raise ImportError("the English / transliterating cleaners need the `unidecode` and `inflect` packages "
-                          "(reference utils/aligner/cleaners.py:1-3); only indic_cleaners() is dependency-free") from e
-    raise NotImplementedError("English / transliterating cleaners are not restated in this build (unpinned: their "
-                              "dependencies are absent from the build image); clean the text upstream or use indic_cleaners()")
+        from unidecode import unidecode
+    except ImportError as e:
+        raise NotImplementedError("transliterating non-ASCII text needs the `unidecode` package (reference "
+                                  "utils/aligner/cleaners.py:3); it is not installed and is not approximated here") from e
+    return unidecode(text)
+
+
+def _normalize_numbers(text: str) -> str:
+    """`normalize_numbers` (cleaners.py:51-112).  Every rule needs a digit, so digit-free text passes through; with digits
+    the wording comes from `inflect`, exactly as in the reference, or not at all."""
+    if not _HAS_DIGIT.search(text):
+        return text
+    try:
+        import inflect
+    except ImportError as e:
+        raise NotImplementedError("spelling out numbers needs the `inflect` package (reference utils/aligner/cleaners.py:2); "
+                                  "it is not installed and is not approximated here") from e
+    eng = inflect.engine()
+
+    def dollars(m):
+        parts = m.group(1).split(".")
+        if len(parts) > 2:
+            return m.group(1) + " dollars"
+        d = int(parts[0]) if parts[0] else 0
+        c = int(parts[1]) if len(parts) > 1 and parts[1] else 0
+        if d and c:
+            return "%s %s, %s %s" % (d, "dollar" if d == 1 else "dollars", c, "cent" if c == 1 else "cents")
+        if d:
+            return "%s %s" % (d, "dollar" if d == 1 else "dollars")
+        if c:
+            return "%s %s" % (c, "cent" if c == 1 else "cents")
+        return "zero dollars"
+
+    def number(m):
+        num = int(m.group(0))
+        if 1000 < num < 3000:
+            if num == 2000:
+                return "two thousand"
+            if 2000 < num < 2010:
+                return "two thousand " + eng.number_to_words(num % 100)
+            if num % 100 == 0:
+                return eng.number_to_words(num // 100) + " hundred"
+            return eng.number_to_words(num, andword="", zero="oh", group=2).replace(", ", " ")
+        return eng.number_to_words(num, andword="")
+
+    text = re.sub(r"([0-9][0-9\,]+[0-9])", lambda m: m.group(1).replace(",", ""), text)
+    text = re.sub(r"£([0-9\,]*[0-9]+)", r"\1 pounds", text)
+    text = re.sub(r"\$([0-9\.\,]*[0-9]+)", dollars, text)
+    text = re.sub(r"([0-9]+\.[0-9]+)", lambda m: m.group(1).replace(".", " point "), text)
+    text = re.sub(r"[0-9]+(st|nd|rd|th)", lambda m: eng.number_to_words(m.group(0)), text)
+    return re.sub(r"[0-9]+", number, text)
+
+
+def english_cleaners(text: str) -> str:
+    """`english_cleaners` (cleaners.py:120-140): transliterate, lowercase, spell numbers, expand abbreviations, squeeze blanks,
+    delete non-printable ASCII and a fixed punctuation set, '&' -> 'and'.  Self-contained for ASCII text without digits."""
+    text = _normalize_numbers(_to_ascii(text).lower())
+    text = collapse_whitespace(expand_abbreviations(text))
+    text = _NON_PRINTABLE.sub("", text)
+    for ch in _ENGLISH_DROP:
+        text = text.replace(ch, "")
+    return text.replace("&", "and")
+
+
+def nonenglish_cleaners(text: str) -> str:
+    """`nonenglish_cleaners` (cleaners.py:142-166), the transliterating pipeline: lowercase, squeeze blanks, delete digits,
+    non-printable ASCII and a fixed punctuation set, '&' -> 'and', trim.  Self-contained for ASCII text."""
+    text = collapse_whitespace(_to_ascii(text).lower())
+    for d in "0123456789":
+        text = text.replace(d, "")
+    text = _NON_PRINTABLE.sub("", text)
+    for ch in _NONENGLISH_DROP:
+        text = text.replace(ch, "")
+    return " ".join(text.replace("&", "and").split())
+
+
+def ascii_cleaners(text: str, english: bool) -> str:
+    """Either of the two pipelines above (kept for callers of the round-1 name)."""
+    return english_cleaners(text) if english else nonenglish_cleaners(text)
 
 
 def text_to_characters(cleaned: str, symbols: Iterable[str]) -> List[str]:

@@ -13,9 +13,12 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "text_cl
 
 @pytest.mark.parametrize("fn,key", [(T.indic_cleaners, "nonenglish_cleaners_no_transliteration"),
                                     (T.replace_devanagari_numbers, "replace_devanagari_numbers"),
-                                    (T.collapse_whitespace, "collapse_whitespace")])
+                                    (T.collapse_whitespace, "collapse_whitespace"),
+                                    (T.english_cleaners, "english_cleaners"),          # ASCII, digit-free inputs
+                                    (T.nonenglish_cleaners, "nonenglish_cleaners"),    # ASCII inputs
+                                    (T.expand_abbreviations, "expand_abbreviations")])
 def test_cleaners_match_reference_outputs(fn, key):
-    assert len(GOLD[key]) >= 10
+    assert len(GOLD[key]) >= 8
     for src, want in GOLD[key]:
         assert fn(src) == want, (key, src)
 
@@ -45,5 +48,24 @@ def test_characters_and_batch_follow_the_demo_notebook():
 
 
 def test_english_path_is_gated_not_faked():
-    with pytest.raises((ImportError, NotImplementedError)):
-        T.ascii_cleaners("Dr. Smith paid $5", english=True)
+    """Beyond ASCII (needs `unidecode`) and, for English, digits (needs `inflect`) the cleaners use the packages when they
+    are importable and otherwise raise -- they never approximate."""
+    try:
+        import inflect  # noqa: F401
+        have_inflect = True
+    except ImportError:
+        have_inflect = False
+    try:
+        import unidecode  # noqa: F401
+        have_unidecode = True
+    except ImportError:
+        have_unidecode = False
+    if not have_inflect:
+        with pytest.raises(NotImplementedError):
+            T.english_cleaners("Dr. Smith paid $5")
+    if not have_unidecode:
+        with pytest.raises(NotImplementedError):
+            T.nonenglish_cleaners("नमस्ते")
+        with pytest.raises(NotImplementedError):
+            T.english_cleaners("café")
+    assert T.ascii_cleaners("Mr. X", english=True) == "mister x" and T.ascii_cleaners("A  1 b", english=False) == "a b"

@@ -29,6 +29,24 @@ CASES = [
     "१२३४५",
 ]
 NUMBERS = [0, 1, 7, 10, 11, 19, 20, 21, 35, 48, 50, 77, 99, 100, 101, 110, 119, 200, 342, 500, 999]
+# ASCII inputs for the English / transliterating pipelines (cleaners.py:120-166).  On ASCII text `unidecode` is the identity
+# (its documented contract) and, without digits, no rule of `normalize_numbers` fires, so the reference's own functions run
+# here WITHOUT either package: `unidecode` is bound to a checked identity that refuses non-ASCII input and `_inflect` to an
+# object that raises on any use -- if either mattered for a case, generating the goldens would fail.
+ENGLISH_CASES = [
+    "Dr. Smith & Mrs. O'Neil met Mr. Brown at St. Mary's.",
+    "The  Hon. Rev. Lt. Col. Gen. Sgt. Capt. Maj. (ret.) spoke;  TTS. Ltd. & Co. Esq. Jr. Drs. Ft. Knox",
+    "UPPER case, Mixed\tWhitespace\n and #hash +plus \\back _under `tick @at /slash -dash 'quote >gt <lt (p) *star \"dq\" :colon ;semi !bang",
+    "mr smith without a dot, mrs.jones, dr.who and a st.bernard",
+    "AT&T & friends --- it's <fine>",
+    "tilde ~ caret ^ pipe | percent % equals = brackets [ ] braces { } question ? comma , period .",
+    "",
+    "   ",
+]
+NONENGLISH_CASES = ENGLISH_CASES + [
+    "namaste duniya 123 times, room 4B | 50% [ok] {x} = y ^ z",
+    "Digits 0123456789 vanish; 'quotes' and \"doubles\" too",
+]
 
 
 def load_reference_functions():
@@ -36,7 +54,15 @@ def load_reference_functions():
     src = re.sub(r"^import inflect\s*$", "", src, flags=re.M)
     src = re.sub(r"^from unidecode import unidecode\s*$", "", src, flags=re.M)
     src = re.sub(r"^_inflect = inflect\.engine\(\)\s*$", "", src, flags=re.M)
-    ns = {}
+    class _NoInflect:
+        def __getattr__(self, name):
+            raise RuntimeError("inflect would be needed for this input: not a dependency-free case")
+
+    def _ascii_identity(text):
+        if not text.isascii():
+            raise RuntimeError("unidecode would be needed for this input: not a dependency-free case")
+        return text
+    ns = {"unidecode": _ascii_identity, "_inflect": _NoInflect()}
     exec(compile(src, REF, "exec"), ns)
     return ns
 
@@ -49,6 +75,9 @@ def main():
         "replace_devanagari_numbers": [[c, ns["replace_devanagari_numbers"](c)] for c in CASES],
         "collapse_whitespace": [[c, ns["collapse_whitespace"](c)] for c in CASES],
         "number_to_hindi": [[n, ns["number_to_hindi"](n)] for n in NUMBERS],
+        "english_cleaners": [[c, ns["english_cleaners"](c)] for c in ENGLISH_CASES],
+        "nonenglish_cleaners": [[c, ns["nonenglish_cleaners"](c)] for c in NONENGLISH_CASES],
+        "expand_abbreviations": [[c.lower(), ns["expand_abbreviations"](c.lower())] for c in ENGLISH_CASES],
     }
     path = os.path.join(ROOT, "tests", "golden", "text_cleaners.json")
     with open(path, "w", encoding="utf-8") as f:
