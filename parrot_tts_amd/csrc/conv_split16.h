@@ -259,16 +259,30 @@ inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// tile variants: 0 = 128 x 128 (waves 2x2, wave tile 64x64 = 4x4 MFMA tiles), 1 = 64 x 192 (waves 1x4, wave tile 64x48)
+// tile variants: 0 = 128 x 128 (waves 2x2, wave tile 64x64 = 4x4 MFMA tiles), 1 = 64 x 192 (waves 1x4, wave tile 64x48);
+//                2 = 128 x 64, 3 = 64 x 64: the same row tiling with a third / half of the columns, for launches that would not
+//                    give every CU a workgroup (small batches): the latency of a workgroup is its K loop x MFMAs per step
 inline void split16_tile(int variant, int& bm, int& bn) {
-    bm = variant ? 64 : 128;
-    bn = variant ? 192 : 128;
+    bm = (variant & 1) ? 64 : 128;
+    bn = variant >= 2 ? 64 : (variant ? 192 : 128);
 }
 // (k = 3: three steps per 32-channel chunk do not amortise the larger slab -- measured 3-6 % slower than conv_split_kernel)
 inline bool split16_has(int scheme, int k) { return scheme == SchF16x3::ID && (k == 7 || k == 9 || k == 11); }
 template <class SCH>
 inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStream_t s) {
-    if (variant) switch (p.k) {
+    if (variant == 2) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 7>(p, s);
+            case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 9>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 11>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    if (variant == 3) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 1, 7>(p, s);
+            case 9: return launch_conv_split16_t<SCH, 1, 4, 4, 1, 9>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 1, 4, 4, 1, 11>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    if (variant == 1) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 7>(p, s);
             case 9: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 9>(p, s);
             case 11: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 11>(p, s);

@@ -527,14 +527,20 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     }
     TileCfg t = tile_cfg(cfg);
     int variant16 = 0;
+    static const bool small_tiles = [] { const char* e = getenv("PARROT_SMALL_TILES"); return !e || atoi(e) != 0; }();
     if (c->mfma16) {
         variant16 = c->M >= 128 ? 0 : 1;
+        split16_tile(variant16, t.bm, t.bn);
+        // small batches: a launch that would not give every CU a workgroup takes the 64-column tiles (2-3x the workgroups,
+        // a half / third of the MFMAs per step: the per-launch latency is what counts there, not the operand reuse)
+        if (small_tiles && (long)((p.Ncols + t.bn - 1) / t.bn) * B * ((c->M + t.bm - 1) / t.bm) < g_num_cus) variant16 += 2;
         split16_tile(variant16, t.bm, t.bn);
     } else if (c->prec >= 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
         // better (76 vs 61 TF on the qkv projection); every other layer is faster on the 64x64 wave tile
         // (and so are sequences of <= 64 steps -- the TTE encoder side -- which would leave half of a 128-column tile empty)
-        variant16 = (cfg == 2) ? 3 : (cfg == 0 && (c->kk == 1 || p.Ncols <= 64)) ? 2 : cfg;
+        const bool few = small_tiles && cfg == 0 && (c->kk == 3 || c->kk == 9) && (long)((p.Ncols + 127) / 128) * B * ((c->M + 127) / 128) < g_num_cus;
+        variant16 = (cfg == 2) ? 3 : (cfg == 0 && (c->kk == 1 || p.Ncols <= 64 || few)) ? 2 : cfg;
         split_tile(variant16, t.bm, t.bn);
     }
     p.tiles_n = (p.Ncols + t.bn - 1) / t.bn;
@@ -543,7 +549,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         // algorithmic work of the layer (real taps only; DESIGN.md "roofline accounting")
         const double macs = (double)B * c->d.c_out * c->Cin * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         const double elems = (double)B * ((double)c->d.c_in * Tin + (double)c->Cout * Tout * (1 + (res ? 1 : 0) + (epi != EPI_STORE ? 1 : 0)));
-        const int row = c->mfma16 ? NUM_TILE_CFGS + 9 + variant16
+        const int row = c->mfma16 ? NUM_TILE_CFGS + 9 + (variant16 & 1)
                                   : (c->prec >= 1) ? (variant16 >= 2 ? NUM_TILE_CFGS + 1 + variant16 : NUM_TILE_CFGS + cfg) : cfg;  // split rows follow the exact ones
         TRY(prof_open(rec, row, 2.0 * macs, 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k), s));
     }
