@@ -152,6 +152,36 @@ def test_conv1d_split_schemes_match_fp64(case, scheme):
     assert e6 <= 4 * e32 + 1e-6, "a split evaluation must stay in the same error class as the exact fp32 kernel"
 
 
+def test_conv1d_fuzz_wide_layers_all_kernel_variants():
+    """Seeded random layer shapes through the default (fp16x3) plans: channel counts / tap counts / dilations that select
+    conv_split16_kernel (k >= 7, C_in % 32 == 0, >= 64 rows: 128- and 64-row tiles, and their 64-column small-batch variants),
+    conv_split_kernel (k = 3, 1, other channel counts) and the exact kernel (odd channel counts), with sequence lengths
+    around every tile boundary, residual / ReLU / leaky-ReLU on and off -- against torch in fp64."""
+    rng = _rng(2024)
+    for case in range(48):
+        cin = int(rng.choice([32, 64, 96, 128, 160, 256, 48, 20]))
+        cout = int(rng.choice([64, 128, 192, 256, 72, 1024]))
+        k = int(rng.choice([1, 3, 7, 9, 11]))
+        dil = int(rng.choice([1, 3, 5])) if k > 1 else 1
+        B = int(rng.integers(1, 4))
+        T = int(rng.choice([1, 15, 63, 64, 65, 127, 128, 129, 191, 193, 255, 257, 300, 511, 640, 700]))
+        pre, res, act = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.choice([0, 0, 1]))
+        w = _randn(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
+        b = _randn(rng, cout, scale=0.1)
+        x = _randn(rng, B, cin, T)
+        r = _randn(rng, B, cout, T) if res else None
+        pad = dil * (k - 1) // 2
+        y_ref = F.conv1d((F.leaky_relu(x, 0.1) if pre else x).double(), w.double(), b.double(), padding=pad, dilation=dil)
+        if act == 1:
+            y_ref = F.relu(y_ref)
+        if res:
+            y_ref = y_ref + r.double()
+        plan = ops.ConvPlan(w, b, dilation=dil, padding=pad, pre_act=int(pre), pre_slope=0.1, act=act, precision=ops.PREC_F16X3)
+        y = plan(x.to(DEV), None if r is None else r.to(DEV)).cpu().double()
+        err = float((y - y_ref).abs().max()) / max(1.0, float(y_ref.abs().max()))
+        assert err <= 2e-5, (case, cin, cout, k, dil, B, T, pre, res, act, err)
+
+
 def test_split_f16_scaling_covers_small_and_large_operands_and_overflows_loudly():
     """The fp16 split pre-scales activations by 2^3 and the layer's weights by a power of two: full relative accuracy for
     tiny weights (1e-6 scale) and activations from 1e-3 to 1e3 in one tensor; beyond fp16's range (|x| >= 8190) the
@@ -563,6 +593,28 @@ def test_vocoder_ragged_batch_rows_equal_single_utterance_runs(cfg_name, prec, f
     y_plain = gen(code=batch["code"].to(DEV), spkr=batch["spkr"].to(DEV)).cpu()
     n = lens[1]
     assert float((y_plain[1, :, : n * hop] - y[1, :, : n * hop]).abs().max()) > 1e-3
+
+
+def test_vocoder_fuzz_full_size_ragged_rows():
+    """Seeded random (batch, units, per-row lengths) on the FULL-SIZE generator in the default mode: every row of the padded
+    batch against the oracle run of that utterance alone -- window / halo / edge handling of all fused and layer kernels at
+    lengths that fall anywhere relative to their tiles."""
+    h = synth.default_voc_config()
+    vsd = synth.synth_voc_state_dict(h, seed=1234)
+    gen = _gen(h, vsd)
+    rng = _rng(77)
+    for case in range(5):
+        B = int(rng.integers(1, 4))
+        U = int(rng.choice([2, 7, 13, 26, 41, 58]))
+        lens = [U] + [int(rng.integers(1, U + 1)) for _ in range(B - 1)]
+        b = synth.synth_voc_batch(B, U, h, seed=100 + case)
+        y = gen(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV), unit_lens=torch.tensor(lens)).cpu()
+        for r, n in enumerate(lens):
+            with torch.no_grad():
+                ref = O.code_generator_forward(vsd, h, b["code"][r:r + 1, :n], b["spkr"][r:r + 1])
+            err = float((y[r:r + 1, :, : n * 320] - ref).abs().max())
+            assert err <= 5e-5, (case, B, U, lens, r, err)
+    gen.check_inputs()
 
 
 def test_chunk_streamed_vocoder_equals_whole_utterance(prec):
