@@ -105,3 +105,12 @@ def test_bench_runs_under_torchrun_with_two_ranks(tmp_path):
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
     assert abs(res["value"] * res["ms_per_step"] / 1e3 - 8 * 256 * 320) < 1.0  # value = all ranks' samples / max-over-ranks time
+
+
+def test_rccl_primitives_of_the_gather_path_single_rank():
+    """The box has one GPU, so RCCL cannot carry a real multi-rank gather here; what CAN be checked is that the exact
+    primitives the N > 1 path uses (`init_process_group('nccl', device_id=...)`, `dist.gather` into views of one buffer,
+    `all_reduce(MAX)`, `barrier`, the gloo side group for shapes) work on this RCCL / torch stack with one rank."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank_check.py")], capture_output=True, text=True, cwd=ROOT,
+                         env=dict(os.environ, GRAFT_REPO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=600)
+    assert out.returncode == 0 and "rccl single-rank primitives ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
