@@ -152,6 +152,10 @@ def main():
     rank, world, local = pdist.init_from_env("nccl")
     if world != a.gpus:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    # one GPU per rank: the only exception is the 2-ranks-on-one-GPU test of the N > 1 path (gloo carries its collective)
+    if world > torch.cuda.device_count() and os.environ.get("PARROT_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} ranks but only {torch.cuda.device_count()} visible GPU(s); one process per GPU "
+                         "(set PARROT_DIST_BACKEND=gloo to share a device in tests)")
     dev = pdist.local_device(local)
     torch.cuda.set_device(dev)
     vocab, n_spk = 300, 10
@@ -176,16 +180,26 @@ def main():
 
         overlap = overlap_steps and workload == "full"
 
+        gather_ev = []  # (start, stop) CUDA events around every gather: the collective's share of a step, reported as gather_ms
+
+        def gather(wav):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = pdist.gather_waveforms(wav, dst=0, equal_shapes=True)  # forced durations: every shard is (B, 1, 320 L)
+            e1.record()
+            gather_ev.append((e0, e1))
+            return r
+
         def finish(out):
             if out is None:
                 return None
-            return pdist.gather_waveforms(out["wav"], dst=0, equal_shapes=True) if world > 1 else out["wav"]
+            return gather(out["wav"]) if world > 1 else out["wav"]
 
         def step():
             if overlap:  # TTE of this batch beside the vocoder of the previous one; results one call late
                 return finish(pipe.submit(batch))
             wav = pipe(batch)["wav"] if workload == "full" else gen(code=vb["code"], spkr=vb["spkr"])
-            return pdist.gather_waveforms(wav, dst=0, equal_shapes=True) if world > 1 else wav  # forced durations: every shard is (B, 1, 320 L)
+            return gather(wav) if world > 1 else wav
 
         def drain():  # every submitted batch is finished inside the region that submitted it
             return finish(pipe.flush()) if overlap else None
@@ -195,6 +209,7 @@ def main():
             wav = step()
         wav = drain() if overlap and warmup else wav
         fence()
+        gather_ev.clear()
         lib.parrot_prof_begin()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -207,9 +222,11 @@ def main():
         names = tile_names(precision)
         prof = (C.c_double * (4 * len(names)))()
         _lib.check(lib.parrot_prof_end(prof, len(names)))
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        g_ms = sum(a_.elapsed_time(b_) for a_, b_ in gather_ev) / max(steps, 1)
+        t = torch.tensor([elapsed, g_ms], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        run.gather_ms = float(t[1].item())
         rows = []
         for i, nm in enumerate(names):
             n, tms, fl, by = prof[4 * i: 4 * i + 4]
@@ -219,7 +236,7 @@ def main():
         rows.sort(key=lambda r: -r["ms_per_step"])
         n_samples = world * B * (wav.shape[-1] if wav is not None else 4 * S * 320)
         del pipe, parrot, gen
-        return float(t.item()), rows, n_samples, (cfg, h, tsd, vsd)
+        return float(t[0].item()), rows, n_samples, (cfg, h, tsd, vsd)
 
     def long_form(precision, steps, B=8, U=1500, chunk=256):
         ops.set_default_precision(ops.PREC_NAMES[precision])
@@ -240,7 +257,39 @@ def main():
         del parrot, gen
         return out
 
+    def driver_e2e(precision, n_items=256, n_single=32):
+        """The shipped vocoder driver end to end (parrot_tts_amd/cli/voc_infer.run_batched): `n_items` utterances of 128-256
+        units -> length-bucketed padded batches -> int16 -> pinned host -> peak-normalise -> WAV files on disk, against the same
+        driver fed one utterance per batch (what reference utils/vocoder/inference.py:146-175 does)."""
+        import numpy as np
+        import shutil
+        from parrot_tts_amd.cli.voc_infer import run_batched
+        ops.set_default_precision(ops.PREC_NAMES[precision])
+        cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
+        rng = np.random.Generator(np.random.PCG64(7))
+        tmp = tempfile.mkdtemp()
+        rows = [(rng.integers(0, h["num_embeddings"], int(rng.integers(128, 257))).astype(np.int64), int(rng.integers(0, 10)),
+                 os.path.join(tmp, f"utt{i:04d}_gen.wav")) for i in range(n_items)]
+        out = {}
+        try:
+            run_batched(gen, rows[:64], dev, SAMPLE_RATE)  # warm-up: workspace, handle, page cache
+            for key, sel, mr in (("batched", rows, 64), ("one_utterance_per_batch", rows[:n_single], 1)):
+                fence()
+                t0 = time.perf_counter()
+                nw = run_batched(gen, sel, dev, SAMPLE_RATE, max_rows=mr)
+                fence()
+                dt = time.perf_counter() - t0
+                out[key] = {"utterances_per_s": nw / dt, "samples_per_s": sum(r[0].size for r in sel) * 320 / dt, "items": nw, "seconds": dt}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        out["speedup"] = out["batched"]["utterances_per_s"] / out["one_utterance_per_batch"]["utterances_per_s"]
+        out["workload"] = ("vocoder driver incl. host post-processing and WAV writing: %d utterances of 128-256 units, length-bucketed "
+                           "batches of <= 64 rows vs one utterance per batch (first %d items)" % (n_items, n_single))
+        del parrot, gen
+        return out
+
     elapsed, rows, n_samples_step, pieces = run(a.precision, a.steps, a.warmup, overlap_steps=bool(a.overlap))
+    gather_ms = run.gather_ms
 
     if rank == 0:
         ms = elapsed / a.steps * 1e3
@@ -275,6 +324,9 @@ def main():
                        "weights": "seeded synthetic, reference checkpoint layouts (TTE seed 42 forced duration 4; vocoder seed 1234)",
                        "note": "reference vocoder is 16 kHz / 320 samples per unit (utils/vocoder/config.json:24,32), not 22.05 kHz"},
             "roofline": roof,
+            # the waveform gather's share of a step (max over ranks, CUDA events around the collective; 0 at N = 1) and what the
+            # process group really is, so a scaling curve can be decomposed into compute and collective
+            "gather_ms": gather_ms, "dist": pdist.dist_info(),
         }
     if rank == 0:
         res["schedule"] = ("two-stage pipeline across steps: the TTE of batch i runs on a side HIP stream beside the vocoder of batch "
@@ -305,6 +357,8 @@ def main():
                                       "workload": "full pipeline, ONE utterance (S=%d -> %d units), BASELINE configs[0] shape" % (S, 4 * S)}
         # BASELINE.json configs[4]: long-form 30 s utterances, batch 8 x 1500 units, chunk-streamed vocoder (256-unit chunks)
         res["long_form_b8_u1500"] = long_form(a.precision, min(a.steps, 5))
+        # the shipped vocoder driver, batched vs one utterance per launch chain (host post-processing included)
+        res["driver_e2e"] = driver_e2e(a.precision)
     if world == 1 and a.precision != "f32" and not a.no_alt:
         # the same workload with every product on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32), for reference
         e2, rows2, n2, _ = run("f32", min(a.steps, 5), 1)

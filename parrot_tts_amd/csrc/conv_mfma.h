@@ -79,9 +79,10 @@ __device__ __forceinline__ float apply_act(float v, int act) { return (act == AC
 static __global__ void tanh_inplace_kernel(float* __restrict__ y, size_t n, int* __restrict__ err) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const float r = tanhf(y[i]);
-        y[i] = r;
-        if (err && !(fabsf(r) <= 1.0f)) atomicExch(err, 5);  // NaN / inf reached the waveform (fp16 split range exceeded)
+        const float v = y[i];
+        y[i] = tanhf(v);
+        // NaN / inf reached the waveform (fp16 split range exceeded).  The PRE-activation is tested: tanhf(+-inf) = +-1 would pass
+        if (err && !(fabsf(v) < INFINITY)) atomicExch(err, 5);
     }
 }
 

@@ -18,7 +18,7 @@ struct ConvValuParams {
     int act;             // ACT_NONE / ACT_TANH
     const int32_t* row_len;
     int row_len_mul;
-    int* err;            // optional device flag: set to 5 when a tanh output is not inside [-1, 1] (NaN / inf reached the waveform)
+    int* err;            // optional device flag: set to 5 when a tanh layer's pre-activation is NaN / inf (it reached the waveform)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t valu_row_rsrc(const float* base) {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void conv1_valu_kernel(const ConvValuParams p)
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         const float r = (p.act == ACT_TANH) ? tanhf(acc[o]) : acc[o];
-        if (p.act == ACT_TANH && p.err && !(fabsf(r) <= 1.0f)) atomicExch(p.err, 5);
+        if (p.act == ACT_TANH && p.err && !(fabsf(acc[o]) < INFINITY)) atomicExch(p.err, 5);  // (pre-tanh: tanhf(inf) = 1 would pass)
         if (t0 + o < p.Tout) yb[t0 + o] = r;
     }
 }
@@ -110,7 +110,7 @@ static __global__ __launch_bounds__(256) void conv1_valu7_vec_kernel(const ConvV
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         r[o] = (p.act == ACT_TANH) ? tanhf(acc[o]) : acc[o];
-        if (p.act == ACT_TANH && p.err && !(fabsf(r[o]) <= 1.0f)) atomicExch(p.err, 5);
+        if (p.act == ACT_TANH && p.err && !(fabsf(acc[o]) < INFINITY)) atomicExch(p.err, 5);  // (pre-tanh: tanhf(inf) = 1 would pass)
     }
     if (t0 + 3 < p.Tout) *reinterpret_cast<f32x4v*>(p.y + (size_t)b * p.Tout + t0) = r;
     else

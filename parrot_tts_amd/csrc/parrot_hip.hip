@@ -23,6 +23,7 @@
 #include "kernels_misc.h"
 #include "resblock_split.h"
 #include "resblock_split16.h"
+#include "resblock_dual.h"
 #include "resblock_fused.h"
 
 using namespace parrot;
@@ -947,7 +948,10 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         if (last && before_last) HIP_TRY(hipStreamWaitEvent(s, before_last, 0));  // the MRF sum is accumulated in branch order
         const bool k16 = v->rb_kind[(size_t)stage * c.n_kernels + j] == 1;
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : k16 ? 11 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
-        HIP_TRY(v->rb_kind[(size_t)stage * c.n_kernels + j] == 1 ? launch_resblock_split16(v->scheme, C, p, s) : launch_resblock_split(v->scheme, C, p, s));
+        // dual-window anti-phase workgroups (resblock_dual.h; PARROT_RB_DUAL=0: one window per workgroup, resblock_split.h)
+        static const bool dual_on = [] { const char* e = getenv("PARROT_RB_DUAL"); return e && atoi(e) != 0; }();
+        HIP_TRY(k16 ? launch_resblock_split16(v->scheme, C, p, s)
+                    : (dual_on && resblock_dual_has(v->scheme, C)) ? launch_resblock_dual_f16x3(C, p, s) : launch_resblock_split(v->scheme, C, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
         src = p.y;
         m0 = m1;

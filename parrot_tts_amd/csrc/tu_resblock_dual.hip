@@ -1,0 +1,6 @@
+// tu_resblock_dual.hip -- one translation unit of libparrot_hip.so (parrot_tts_amd/build.py compiles them in parallel): the
+// dual-window anti-phase fused ResBlock pair kernels (resblock_dual.h) for the default scheme.
+#include "resblock_dual.h"
+namespace parrot {
+hipError_t launch_resblock_dual_f16x3(int C, const ResblockSplitParams& p, hipStream_t s) { return launch_resblock_dual_s<SchF16x3>(C, p, s); }
+}  // namespace parrot

@@ -107,7 +107,7 @@ def gather_waveforms(wav: torch.Tensor, dst: int = 0, equal_shapes: bool = False
             _gather_buf.clear()  # one live shape: do not pin the memory of shapes long gone
             _gather_buf[key] = torch.empty((world, bmax, nmax), dtype=wav.dtype, device=send.device)
         out = list(_gather_buf[key].unbind(0))
-    dist.gather(send, out, dst=dst)
+    _collect(send, out, dst, key if rank == dst else None)
     lens_all = None
     if n_samples is not None:
         lens_all = [torch.empty(s[0], dtype=torch.int64) for s in shapes] if rank == dst else None
@@ -122,6 +122,53 @@ def gather_waveforms(wav: torch.Tensor, dst: int = 0, equal_shapes: bool = False
     if host_staged:
         res = res.to(wav.device)
     return res if n_samples is None else (res, lens_all)
+
+
+_gather_mode = os.environ.get("PARROT_GATHER", "auto")  # auto | gather | allgather
+_allgather_buf: Dict[tuple, torch.Tensor] = {}
+
+
+def _collect(send: torch.Tensor, out, dst: int, key) -> None:
+    """Move every rank's (bmax, nmax) shard into the root's receive buffer.  `dist.gather` into the `unbind` views of ONE
+    contiguous buffer (grouped send / recv under RCCL: each peer uses its own xGMI link to the root).  Should a backend
+    reject the view list, PARROT_GATHER=auto falls back -- once, for the rest of the process, on all ranks together -- to
+    `all_gather_into_tensor` on a single contiguous tensor (every rank then holds a copy: world x 21 MB at B = 64)."""
+    global _gather_mode
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if _gather_mode in ("auto", "gather"):
+        ok = 1
+        try:
+            dist.gather(send, out, dst=dst)
+        except RuntimeError:
+            if _gather_mode == "gather":
+                raise
+            ok = 0
+        if _gather_mode == "gather":
+            return
+        # all ranks must agree on the fallback (a failure on the root only would otherwise deadlock the next call)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_meta_pg())
+        if int(flag) == 1:
+            return
+        _gather_mode = "allgather"
+        if rank == 0:
+            print("parrot_tts_amd.dist: dist.gather into buffer views failed; using all_gather_into_tensor from now on", flush=True)
+    k2 = (world,) + tuple(send.shape) + (send.dtype, str(send.device))
+    if k2 not in _allgather_buf:
+        _allgather_buf.clear()
+        _allgather_buf[k2] = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+    full = _allgather_buf[k2]
+    dist.all_gather_into_tensor(full, send)
+    if rank == dst:
+        _gather_buf[key].copy_(full)
+
+
+def dist_info() -> dict:
+    """What the process group actually is (for bench.py's JSON line): backend, ranks, devices visible to this process."""
+    if not dist.is_initialized():
+        return {"backend": None, "nranks": 1, "device_count": torch.cuda.device_count()}
+    return {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "device_count": torch.cuda.device_count(),
+            "gather": _gather_mode}
 
 
 def _gather_host_rows(mine: torch.Tensor, out, shapes, dst):

@@ -231,11 +231,10 @@ class CodeGenerator(nn.Module):
         return f
 
     # ---- forward ------------------------------------------------------------------------------
-    @torch.no_grad()
-    def forward(self, stages: Optional[dict] = None, unit_lens: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
-        """``generator(code=..., spkr=...)`` as in the reference.  ``unit_lens`` (B,) int: real units per row of a padded
-        (ragged) batch -- every layer then zero-pads at each row's own end, so ``wav[b, :, :unit_lens[b]*hop]`` equals the
-        reference run of that utterance alone (the reference vocoder driver is B=1 only)."""
+    def _checked_inputs(self, kwargs, unit_lens):
+        """Validate what the C ABI takes as raw device pointers (shared by ``forward`` and the native chunked path): ``code``
+        (B, U) int64 on the GPU, ``spkr`` int64 with B entries (multi-speaker models), ``unit_lens`` with B entries.
+        Returns contiguous (code, spkr or None, unit_lens as int32 or None)."""
         code = kwargs["code"]
         require_cuda(code, "code")
         if code.dim() != 2 or code.dtype != torch.int64:
@@ -246,14 +245,22 @@ class CodeGenerator(nn.Module):
             spkr = kwargs["spkr"].to(dev).reshape(-1).contiguous()
             if spkr.dtype != torch.int64 or spkr.numel() != code.shape[0]:
                 raise ValueError("spkr must be a LongTensor of shape (B, 1)")
-        self._current_handle(dev)
-        code = code.contiguous()
-        B, U = code.shape
         lens32 = None
         if unit_lens is not None:
             lens32 = unit_lens.to(dev, torch.int32).contiguous()
-            if lens32.numel() != B:
+            if lens32.numel() != code.shape[0]:
                 raise ValueError("unit_lens must have one entry per batch row")
+        return code.contiguous(), spkr, lens32
+
+    @torch.no_grad()
+    def forward(self, stages: Optional[dict] = None, unit_lens: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+        """``generator(code=..., spkr=...)`` as in the reference.  ``unit_lens`` (B,) int: real units per row of a padded
+        (ragged) batch -- every layer then zero-pads at each row's own end, so ``wav[b, :, :unit_lens[b]*hop]`` equals the
+        reference run of that utterance alone (the reference vocoder driver is B=1 only)."""
+        code, spkr, lens32 = self._checked_inputs(kwargs, unit_lens)
+        dev = code.device
+        self._current_handle(dev)
+        B, U = code.shape
         # extra conditioning keywords (models.py:162-167): everything but code / spkr / f0 (f0 is skipped by the reference
         # too) is upsampled to U frames and concatenated, in keyword order, behind the embeddings
         feats, n_feat = None, 0
@@ -325,13 +332,10 @@ class CodeGenerator(nn.Module):
         runs inside the library (``parrot_voc_forward_chunked``); otherwise it is assembled from ``stream`` chunks."""
         code = kwargs["code"]
         if not [k for k in kwargs if k not in ("code", "spkr", "f0")] and self._in_dim == self._emb_dim * (2 if self.multispkr else 1):
-            require_cuda(code, "code")
+            code, spkr, lens32 = self._checked_inputs(kwargs, unit_lens)  # (raw pointers cross the ABI below)
             dev = code.device
             self._current_handle(dev)
-            code = code.contiguous()
             B, U = code.shape
-            spkr = kwargs["spkr"].to(dev).reshape(-1).contiguous() if self.multispkr else None
-            lens32 = None if unit_lens is None else unit_lens.to(dev, torch.int32).contiguous()
             halo = -1 if halo_units is None else int(halo_units)
             lib = _lib.lib()
             key = ("chunked", B, int(chunk_units), halo)

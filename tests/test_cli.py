@@ -75,3 +75,19 @@ def test_tte_infer_duration_field(tmp_path):
     assert tte_infer.wav_seconds(str(tmp_path / "missing.wav"), 2.5) == 2.5
     with pytest.raises(SystemExit):
         tte_infer.main([])
+
+
+def test_plan_batches_covers_every_row_once_within_the_limits():
+    from parrot_tts_amd.cli.voc_infer import plan_batches
+    import random
+    rnd = random.Random(3)
+    for _ in range(50):
+        lens = [rnd.randint(1, 400) for _ in range(rnd.randint(1, 90))]
+        mr, mu = rnd.randint(1, 20), rnd.randint(50, 3000)
+        plan = plan_batches(lens, mr, mu)
+        assert sorted(i for b in plan for i in b) == list(range(len(lens)))
+        for b in plan:
+            longest = max(lens[i] for i in b)
+            assert len(b) <= mr and (len(b) == 1 or len(b) * longest <= mu)
+            assert lens[b[0]] == longest  # longest first: the first row sizes the padded batch
+    assert plan_batches([], 4, 100) == []

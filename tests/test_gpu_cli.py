@@ -63,6 +63,37 @@ def test_voc_infer_vc_writes_ten_wavs_equal_to_single_calls(tmp_path):
     assert sorted(os.listdir(out2)) == ["hi_f_0001_gt.wav", "hi_f_0001_hi_f_gen.wav"]
 
 
+def test_voc_infer_batched_driver_writes_byte_identical_wavs(tmp_path):
+    """The length-bucketed batched driver against the same driver fed one row per batch: 37 ragged items x
+    (--vc) ten speakers through padded batches with per-row unit counts must give byte-identical WAV files."""
+    h = synth.small_voc_config()
+    h["sampling_rate"] = 16000
+    cfg = tmp_path / "config.json"
+    cfg.write_text(json.dumps(h))
+    vsd = synth.synth_voc_state_dict(h, seed=31)
+    torch.save({"generator": vsd}, tmp_path / "g_00000001")
+    rng = np.random.Generator(np.random.PCG64(5))
+    recs = [{"audio": str(tmp_path / "wavs" / f"hi_f_{i:04d}.wav"), "hubert": " ".join(map(str, rng.integers(0, 100, int(rng.integers(1, 60))))),
+             "duration": 0.1} for i in range(37)]
+    man = tmp_path / "predictions.txt"
+    man.write_text("".join(data.format_dict_line(r) for r in recs))
+    outs = {}
+    for tag, extra in (("batched", ["--batch_rows", "48", "--batch_units", "1500"]), ("single", ["--batch_rows", "1"])):
+        out = tmp_path / tag
+        voc_infer.main(["--checkpoint_file", str(tmp_path / "g_00000001"), "--config", str(cfg), "--input_code_file", str(man),
+                        "--output_dir", str(out), "--vc"] + extra)
+        outs[tag] = out
+    files = sorted(os.listdir(outs["batched"]))
+    assert files == sorted(os.listdir(outs["single"])) and len(files) == 370
+    for f in files:
+        assert (outs["batched"] / f).read_bytes() == (outs["single"] / f).read_bytes(), f
+    # batches really were padded and ragged
+    lens = [len(r["hubert"].split(" ")) for r in recs for _ in range(10)]
+    plan = voc_infer.plan_batches(lens, 48, 1500)
+    assert sorted(i for b in plan for i in b) == list(range(370)) and max(len(b) for b in plan) > 10
+    assert all(len(b) <= 48 and len(b) * max(lens[i] for i in b) <= 1500 for b in plan)
+
+
 def test_tte_infer_writes_predictions_in_the_reference_format(tmp_path):
     root = tmp_path / "tte"
     root.mkdir()

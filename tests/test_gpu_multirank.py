@@ -105,6 +105,15 @@ def test_bench_runs_under_torchrun_with_two_ranks(tmp_path):
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
     assert abs(res["value"] * res["ms_per_step"] / 1e3 - 8 * 256 * 320) < 1.0  # value = all ranks' samples / max-over-ranks time
+    # the fields a scaling curve is decomposed with: what the process group is, and the collective's share of a step
+    assert res["dist"]["nranks"] == 2 and res["dist"]["backend"] == "gloo" and res["dist"]["device_count"] >= 1
+    assert 0.0 < res["gather_ms"] < res["ms_per_step"]
+    # ... and more ranks than GPUs is refused unless the test backend is asked for
+    env2 = {k: v for k, v in env.items() if k != "PARROT_DIST_BACKEND"}
+    cmd2 = [c if c != cmd[cmd.index("--master-port") + 1] else str(_free_port()) for c in cmd]
+    out2 = subprocess.run(cmd2, capture_output=True, text=True, cwd=ROOT, env=env2, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert out2.returncode != 0 and "one process per GPU" in (out2.stderr + out2.stdout)
 
 
 def test_rccl_primitives_of_the_gather_path_single_rank():

@@ -6,8 +6,9 @@ Tolerances (fp32 path):
   * single conv layer      : |diff| <= 2e-5 * max|y|   (different summation order only)
   * vocoder waveform       : max-abs <= 5e-5 of full scale on the realistic-scale weights (the
                              reference's own fp32-vs-fp64 error there is 7e-6).  The "hot" golden (weight scale 1.2,
-                             rms 0.98, tanh saturated everywhere) is a stress case with pre-tanh magnitudes ~1e2 and
-                             is held to 5e-4.
+                             rms 0.98, tanh saturated everywhere) is a stress case with pre-tanh magnitudes ~1e2: the
+                             reference's own fp32 result is 1.2e-4 off an fp64 run there, and the HIP waveform is held
+                             to <= 3x that distance from the fp64 run (measured: 2.5e-4 from the golden).
   * TTE log-durations      : 2e-5 abs;  durations exact where |frac-0.5| > 1e-4
   * TTE unit ids           : bit-exact where the top-2 logit margin > 1e-4 (all goldens satisfy it)
 """
@@ -300,8 +301,22 @@ def test_vocoder_matches_reference_golden(golden_dir, name, prec, fused):
             got = st[k[6:]].cpu().numpy()
             assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max()), k
     err = float(np.abs(y.cpu().numpy() - z["wav"]).max())
-    _report(test="vocoder_golden", name=name, precision=prec, fused=int(fused), wav_max_abs_err=err)
-    assert err <= (5e-4 if name.endswith("_hot") else 5e-5), f"waveform max-abs error {err}"
+    if name.endswith("_hot"):
+        # Stress case (weights x 1.2, pre-tanh magnitudes ~1e2, rms 0.98): the reference's OWN fp32 result is 1.2e-4 away from
+        # exact arithmetic here, so "distance to the fp32 golden" mostly measures the golden.  The yardstick is an fp64 run of
+        # the oracle: the HIP waveform may be at most 3x as far from it as the reference's fp32 waveform is (and the distance to
+        # the golden at most the sum of the two).
+        with torch.no_grad():
+            ref64 = O.code_generator_forward({k: v.double() for k, v in sd.items()}, h, torch.from_numpy(z["code"]), torch.from_numpy(z["spkr"])).numpy()
+        ref_err = float(np.abs(z["wav"].astype(np.float64) - ref64).max())
+        hip_err = float(np.abs(y.cpu().numpy().astype(np.float64) - ref64).max())
+        _report(test="vocoder_golden", name=name, precision=prec, fused=int(fused), wav_max_abs_err=err, hip_vs_fp64=hip_err,
+                reference_fp32_vs_fp64=ref_err)
+        assert hip_err <= 3.0 * ref_err, f"HIP vs fp64 {hip_err} > 3 x reference fp32 vs fp64 {ref_err}"
+        assert err <= 4.0 * ref_err, f"waveform max-abs error {err} vs the fp32 golden (reference's own error {ref_err})"
+    else:
+        _report(test="vocoder_golden", name=name, precision=prec, fused=int(fused), wav_max_abs_err=err)
+        assert err <= 5e-5, f"waveform max-abs error {err}"
     # int16 PCM as the reference driver emits it: allow +-1 LSB where the fp32 error straddles an integer
     pcm = ops.wav_to_int16(y.squeeze(1)).cpu().numpy().astype(np.int32)
     assert np.abs(pcm - z["wav_int16"].astype(np.int32)).max() <= (20 if name.endswith("_hot") else 2)

@@ -27,10 +27,20 @@ def main():
         rows = cur.execute("select name, grid_x / workgroup_x, grid_y / workgroup_y, count(*), sum(duration), avg(duration) from kernels "
                            "group by 1, 2, 3 order by 5 desc").fetchall()
         total = sum(r[4] for r in rows) or 1
+        pmc = {}
+        try:
+            for name, gx, gy, cname, val in cur.execute(
+                    "select k.name, k.grid_x / k.workgroup_x, k.grid_y / k.workgroup_y, p.counter_name, sum(p.counter_value) from pmc_events p "
+                    "join kernels k on p.dispatch_id = k.dispatch_id group by 1, 2, 3, 4"):
+                pmc.setdefault((name, gx, gy), {})[cname] = val
+        except sqlite3.Error:
+            pass
+        counters = sorted({c for v in pmc.values() for c in v})
         w = csv.writer(open(a.csv, "w", newline="") if a.csv else sys.stdout)
-        w.writerow(["kernel", "wg_x", "wg_y", "calls", "total_ms", "avg_us", "pct"])
+        w.writerow(["kernel", "wg_x", "wg_y", "calls", "total_ms", "avg_us", "pct"] + [c + "_per_call" for c in counters])
         for name, gx, gy, n, tot, avg in rows:
-            w.writerow([short(name), gx, gy, n, round(tot / 1e6, 4), round(avg / 1e3, 2), round(100.0 * tot / total, 2)])
+            w.writerow([short(name), gx, gy, n, round(tot / 1e6, 4), round(avg / 1e3, 2), round(100.0 * tot / total, 2)] +
+                       [(pmc[(name, gx, gy)][c] / n if (name, gx, gy) in pmc and c in pmc[(name, gx, gy)] else "") for c in counters])
         return
     rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by 3 desc").fetchall()
     total = sum(r[2] for r in rows) or 1
