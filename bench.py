@@ -149,13 +149,15 @@ def main():
                          "bf16x6 and f32 are parity-grade; bf16 / f16 are the single-MFMA reduced-precision operating point")
     a = ap.parse_args()
 
+    # one GPU per rank (checked before RCCL is brought up): the only exception is the 2-ranks-on-one-GPU test of the N > 1 path,
+    # where gloo carries the collective
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world > torch.cuda.device_count() and os.environ.get("PARROT_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py: WORLD_SIZE={env_world} ranks but only {torch.cuda.device_count()} visible GPU(s); one process per GPU "
+                         "(set PARROT_DIST_BACKEND=gloo to share a device in tests)")
     rank, world, local = pdist.init_from_env("nccl")
     if world != a.gpus:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    # one GPU per rank: the only exception is the 2-ranks-on-one-GPU test of the N > 1 path (gloo carries its collective)
-    if world > torch.cuda.device_count() and os.environ.get("PARROT_DIST_BACKEND") != "gloo":
-        raise SystemExit(f"bench.py: WORLD_SIZE={world} ranks but only {torch.cuda.device_count()} visible GPU(s); one process per GPU "
-                         "(set PARROT_DIST_BACKEND=gloo to share a device in tests)")
     dev = pdist.local_device(local)
     torch.cuda.set_device(dev)
     vocab, n_spk = 300, 10

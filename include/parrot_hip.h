@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PARROT_ABI_VERSION 2
+#define PARROT_ABI_VERSION 3
 
 enum {
     PARROT_OK = 0,
@@ -165,7 +165,7 @@ int parrot_voc_forward_feats(parrot_voc_t*, const int64_t* code, const int64_t* 
                              const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out, float* const* stage_out, void* ws,
                              size_t ws_bytes, void* stream);
 /* Chunk-streamed synthesis (long-form utterances, BASELINE configs[4]): chunks of `chunk_units` units are vocoded with
- * `halo_units` units of real context on both sides (< 0: the generator's receptive field, 20 units = 6 400 samples) and only
+ * `halo_units` units of real context on both sides (< 0: the generator's receptive field, parrot_voc_receptive_units: 21 units for the shipped config) and only
  * their own samples land in wav_out (B,1,U*hop): equal to parrot_voc_forward on the whole utterance to fp32 round-off, with
  * the activation memory of chunk_units + 2*halo_units units.  Not for models with extra conditioning streams. */
 size_t parrot_voc_chunked_workspace_bytes(const parrot_voc_t*, int32_t B, int32_t chunk_units, int32_t halo_units);
@@ -175,6 +175,13 @@ int parrot_voc_forward_chunked(parrot_voc_t*, const int64_t* code, const int64_t
  * outside the embedding tables (the reference's IndexError), PARROT_E_NONFINITE when a waveform sample left [-1, 1] as NaN /
  * inf (an activation beyond the fp16 split scheme's range: never a silently wrong finite value). */
 int parrot_voc_check(parrot_voc_t*, void* stream);
+/* The same flag WITHOUT a synchronisation: copies its value (0 = ok, 1 / 2 bad unit / speaker id, 5 non-finite sample) to
+ * dst_dev[0] (device memory) on `stream` and clears it -- for callers that fetch it with a device-to-host copy they do anyway. */
+int parrot_voc_status_async(parrot_voc_t*, int32_t* dst_dev, void* stream);
+/* Receptive field of the generator in units, either side of an output frame, from the handle's configuration (interval
+ * propagation through conv_post, the MRF stages, the transposed convs of reference utils/vocoder/models.py:80-83 and conv_pre):
+ * 21 for the shipped config.  The default halo of parrot_voc_forward_chunked. */
+int parrot_voc_receptive_units(const parrot_voc_t*);
 /* wav (n) fp32 -> int16 as `(x*32768).astype('int16')` does (utils/vocoder/inference.py:71-73) */
 int parrot_wav_to_int16(const float* wav, int16_t* out, size_t n, void* stream);
 
@@ -231,6 +238,8 @@ int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L,
  * reference's Embedding IndexError) or PARROT_E_NONFINITE (NaN / inf logits at some position of the last decode: an
  * activation beyond the fp16 split scheme's range -- the ids of that call are not to be trusted). */
 int parrot_tte_check(parrot_tte_t*, void* stream);
+/* The same flag without a synchronisation (3 / 4 bad phone / speaker id, 5 non-finite logits): see parrot_voc_status_async. */
+int parrot_tte_status_async(parrot_tte_t*, int32_t* dst_dev, void* stream);
 /* Tests / error localisation: while set, the next encode / decode calls copy the channel-first (B, D, T) activation
  * after each stage to the given DEVICE buffers (NULL entries are skipped): enc_ptrs[0] = embedding + pe[S],
  * enc_ptrs[1 + n] = encoder block n, enc_ptrs[1 + enc_layers] = encoder output (+ speaker); dec_ptrs[0] = length

@@ -85,6 +85,8 @@ SIGNATURES = {
     "parrot_voc_chunked_workspace_bytes": (sz, [vp, i32, i32, i32]),
     "parrot_voc_forward_chunked": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "parrot_voc_check": (C.c_int, [vp, vp]),
+    "parrot_voc_status_async": (C.c_int, [vp, vp, vp]),
+    "parrot_voc_receptive_units": (C.c_int, [vp]),
     "parrot_wav_to_int16": (C.c_int, [vp, vp, sz, vp]),
     "parrot_tte_create": (C.c_int, [C.POINTER(vp), C.POINTER(TteCfg), C.POINTER(TteWeights)]),
     "parrot_tte_destroy": (None, [vp]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "parrot_tte_encode": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_decode": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_check": (C.c_int, [vp, vp]),
+    "parrot_tte_status_async": (C.c_int, [vp, vp, vp]),
     "parrot_tte_debug_stages": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "parrot_length_regulator_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "parrot_length_regulator": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
@@ -116,7 +119,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.parrot_abi_version() != 2:
+        if handle.parrot_abi_version() != 3:
             raise ImportError("libparrot_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -23,15 +23,17 @@ def _stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    """Compile csrc/*.hip -> parrot_tts_amd/libparrot_hip.so.  Returns the library path."""
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: str = None, obj_dir: str = None) -> str:
+    """Compile csrc/*.hip -> parrot_tts_amd/libparrot_hip.so.  Returns the library path.
+    `lib_path` / `obj_dir` / `extra_flags`: experiment builds of the same sources (tools/build_exp.sh -> build_exp/)."""
+    if lib_path is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(OBJ, exist_ok=True)
+    LIB_OUT, OBJ_OUT = lib_path or LIB, obj_dir or OBJ
+    os.makedirs(OBJ_OUT, exist_ok=True)
 
     def compile_one(src):
-        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(OBJ_OUT, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -40,12 +42,19 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_OUT] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return LIB_OUT
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--exp" in sys.argv:  # python -m parrot_tts_amd.build --exp TAG -DFOO -DBAR ...  ->  build_exp/libparrot_TAG.so
+        i = sys.argv.index("--exp")
+        tag, flags = sys.argv[i + 1], sys.argv[i + 2:]
+        root = os.path.dirname(HERE)
+        print(build(force=True, verbose=False, extra_flags=flags, lib_path=os.path.join(root, "build_exp", f"libparrot_{tag}.so"),
+                    obj_dir=os.path.join(root, "build_exp", "obj_" + tag)))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -437,11 +437,10 @@ inline hipError_t launch_attn_flash_t(const AttnParams& p, int B, hipStream_t s)
     constexpr int MT = (HD + 31) / 32;
     const size_t lds = (size_t)2 * 2 * (32 * (HD * 2 + 16) + MT * 32 * (32 * 2 + 8));
     auto kern = attn_flash_kernel<HD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
+    {
+        hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), (size_t)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((p.T + 127) / 128, B * p.H), dim3(256), lds, s, p);
     return hipGetLastError();

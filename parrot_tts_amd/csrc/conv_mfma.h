@@ -27,6 +27,23 @@
 
 namespace parrot {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember it per (kernel instantiation, device), not per
+// process -- a second device in the same process would otherwise launch with the 64 KiB default and fail.
+struct DynLdsOnce {
+    bool done[64] = {};
+};
+inline hipError_t ensure_dyn_lds(DynLdsOnce& st, const void* kern, size_t lds) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && st.done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && tracked) st.done[dev] = true;
+    return e;
+}
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -422,11 +439,10 @@ __host__ inline TileCfg tile_cfg(int id) {
 template <int WAVES_M, int WAVES_N, int WM, int WN, int CI, int MINW>
 inline hipError_t launch_conv_t(const ConvParams& p, dim3 grid, size_t lds, hipStream_t s) {
     auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, WM, WN, CI, MINW>;
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in (gfx950 has 160 KiB per CU)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
+    {
+        hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), (size_t)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, p);
     return hipGetLastError();

@@ -180,11 +180,10 @@ inline hipError_t launch_conv_mfma16(const ConvParams& p, hipStream_t s) {
     constexpr int BN = 4 * MFMA16_NT16 * 16;
     const size_t lds = (size_t)2 * 16 * (BN + CONV_HALO + 16) * sizeof(float);
     auto kern = conv_mfma16_kernel<MFMA16_NT16, 2>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
+    {
+        hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), (size_t)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.B), dim3(256), lds, s, p);
     return hipGetLastError();

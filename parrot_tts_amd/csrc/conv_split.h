@@ -459,11 +459,10 @@ inline hipError_t launch_conv_split_t(const ConvParams& p, dim3 grid, hipStream_
     constexpr int BN = WAVES_N * WN * 32;
     const size_t lds = (size_t)2 * SUBS * SCH::NP * (BN + ((SUBS > 1 && K == 1) ? 0 : CONV_HALO)) * 32;
     auto kern = conv_split_kernel<SCH, WAVES_M, WAVES_N, WM, WN, MINW, K, SUBS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
+    {
+        hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), (size_t)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, p);
     return hipGetLastError();

@@ -248,11 +248,10 @@ inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16, COLS = (BN + CONV_HALO + 63) / 64 * 64;
     const size_t lds = (size_t)2 * SCH::NP * 4 * COLS * 16;
     auto kern = conv_split16_kernel<SCH, WAVES_M, WAVES_N, TM, TN, K>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
+    {
+        hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), (size_t)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const unsigned tiles = (unsigned)p.tiles_n * p.B, n_mb = (p.M + BM - 1) / BM;
     hipLaunchKernelGGL(kern, dim3((tiles + 7) / 8 * 8 * n_mb), dim3(WAVES_M * WAVES_N * 64), lds, s, p);

@@ -941,6 +941,12 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
             static const int stag = [] { const char* e = getenv("PARROT_STAGGER"); return e ? atoi(e) : 0; }();
             static const int stag16 = [] { const char* e = getenv("PARROT_STAGGER16"); return e ? atoi(e) : -1; }();
             p.stagger = (C == 16 && stag16 >= 0) ? stag16 : stag;
+#ifdef RBD_TRACE
+            {   // experiment builds: PARROT_RBD_TRACE_SEL = 100 * channels + taps selects the launches that record their phases
+                static const int sel = [] { const char* e = getenv("PARROT_RBD_TRACE_SEL"); return e ? atoi(e) : 0; }();
+                p.stagger = (sel == 100 * C + k) ? 1 : 0;
+            }
+#endif
             p.first_round = g_num_cus * (scheme_pieces(v->scheme) == 3 ? 2 : 3);
         }
         ProfRec rec{};
@@ -948,10 +954,12 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         if (last && before_last) HIP_TRY(hipStreamWaitEvent(s, before_last, 0));  // the MRF sum is accumulated in branch order
         const bool k16 = v->rb_kind[(size_t)stage * c.n_kernels + j] == 1;
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : k16 ? 11 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
-        // dual-window anti-phase workgroups (resblock_dual.h; PARROT_RB_DUAL=0: one window per workgroup, resblock_split.h)
-        static const bool dual_on = [] { const char* e = getenv("PARROT_RB_DUAL"); return e && atoi(e) != 0; }();
+        // PARROT_RB_DUAL (experiments, resblock_dual.h; measured slower): 0 (default) the kernels of
+        // resblock_split.h, 1 the lean-VALU variant with one window per workgroup, 2 dual-window anti-phase workgroups
+        static const int dual_mode = [] { const char* e = getenv("PARROT_RB_DUAL"); return e ? atoi(e) : 0; }();
         HIP_TRY(k16 ? launch_resblock_split16(v->scheme, C, p, s)
-                    : (dual_on && resblock_dual_has(v->scheme, C)) ? launch_resblock_dual_f16x3(C, p, s) : launch_resblock_split(v->scheme, C, p, s));
+                    : (dual_mode > 0 && resblock_dual_has(v->scheme, C)) ? launch_resblock_dual_f16x3(C, dual_mode == 2 ? 2 : 1, p, s)
+                                                                          : launch_resblock_split(v->scheme, C, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
         src = p.y;
         m0 = m1;
@@ -960,14 +968,49 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
     return PARROT_OK;
 }
 
+// MRF branches that run concurrently for this shape: the handle's stream count, or one above B x U = 8192 units in auto mode
+// (one rule for the workspace size and for the forward pass)
+static int voc_streams(const parrot_voc* v, int B, int U) { return (v->mrf_auto && (long)B * U > 8192) ? 1 : v->mrf_streams; }
+
 extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t U) {
     if (!v || B <= 0 || U <= 0) return 0;
     Arena a(nullptr, 0);
     a.take<float>((size_t)B * v->cfg.model_in_dim * U);
     const size_t mx = voc_max_act(v, B, U);
-    for (int i = 0; i < 3 + 3 * v->mrf_streams; ++i) a.take<float>(mx);  // stage in / ups out / MRF sum + (T1, RA, RB) per concurrent branch
+    for (int i = 0; i < 3 + 3 * voc_streams(v, B, U); ++i) a.take<float>(mx);  // stage in / ups out / MRF sum + (T1, RA, RB) per concurrent branch
     return align_up(a.off, 256);
 }
+
+// Receptive field of the generator in units, either side of an output frame: the interval [tau, tau] of one waveform sample is
+// propagated back through conv_post, every MRF stage (the widest ResBlock), every ConvTranspose1d (tau = t u - p + kappa) and
+// conv_pre, for every phase tau mod hop; a chunk computed with this much real context equals the whole-utterance forward.
+static int voc_receptive_units(const parrot_voc* v) {
+    const parrot_voc_cfg& c = v->cfg;
+    const long hop = v->up_total, base = 4096;  // far from the origin: integer divisions below see positive numbers only
+    long worst = 0;
+    for (long ph = 0; ph < hop; ++ph) {
+        long lo = base * hop + ph, hi = lo;
+        lo -= 3; hi += 3;  // conv_post (k = 7)
+        for (int i = c.n_stages - 1; i >= 0; --i) {
+            long reach = 0;  // widest ResBlock of the stage: sum over its convs of (k - 1) / 2 * dilation
+            for (int j = 0; j < c.n_kernels; ++j) {
+                const long hk = (c.resblock_kernel_sizes[j] - 1) / 2;
+                long r = 0;
+                for (int m = 0; m < c.n_dil; ++m) r += hk * c.resblock_dilation_sizes[j][m] + (c.resblock_type == 1 ? hk : 0);
+                reach = std::max(reach, r);
+            }
+            lo -= reach; hi += reach;
+            const long u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i], p = (k - u) / 2;
+            // output tau depends on inputs t with tau = t u - p + kappa, kappa in [0, k): t in [ceil((tau + p - k + 1) / u), floor((tau + p) / u)]
+            lo = (lo + p - k + 1 + u - 1) / u;
+            hi = (hi + p) / u;
+        }
+        lo -= 3; hi += 3;  // conv_pre (k = 7)
+        worst = std::max(worst, std::max(base - lo, hi - base));
+    }
+    return (int)worst;
+}
+extern "C" int parrot_voc_receptive_units(const parrot_voc_t* v) { return v ? voc_receptive_units(v) : PARROT_E_INVALID; }
 
 static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_stride, const int64_t* spkr, const float* feats,
                             int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
@@ -985,13 +1028,13 @@ extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, co
 }
 
 // Chunk-streamed synthesis inside the library (`chunk_units`; BASELINE configs[4]): consecutive chunks of
-// `chunk_units` units are vocoded with `halo_units` (< 0: the generator's receptive field, 20) of real context on both
-// sides and only their own samples are copied into wav_out -- equal to the whole-utterance forward to fp32 round-off,
-// with the activation memory of chunk_units + 2 halo_units units.  Chunks that touch a true sequence edge contain the edge.
-static const int VOC_RECEPTIVE_UNITS = 20;
+// `chunk_units` units are vocoded with `halo_units` (< 0: the generator's receptive field, computed from the config: 21 units
+// for the shipped one) of real context on both sides and only their own samples are copied into wav_out -- equal to the
+// whole-utterance forward, with the activation memory of chunk_units + 2 halo_units units.  Chunks that touch a true sequence
+// edge contain the edge.
 extern "C" size_t parrot_voc_chunked_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t chunk_units, int32_t halo_units) {
     if (!v || B <= 0 || chunk_units <= 0) return 0;
-    const int halo = halo_units < 0 ? VOC_RECEPTIVE_UNITS : halo_units;
+    const int halo = halo_units < 0 ? voc_receptive_units(v) : halo_units;
     const int span = chunk_units + 2 * halo;
     Arena a(nullptr, 0);
     a.take<float>((size_t)B * span * v->up_total);
@@ -1006,7 +1049,7 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
     if (B <= 0 || U <= 0 || chunk_units <= 0) return fail(PARROT_E_INVALID, "voc_forward_chunked: empty batch or chunk");
     if (v->cfg.model_in_dim != v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1))
         return fail(PARROT_E_UNSUPPORTED, "voc_forward_chunked: models with extra conditioning streams go through parrot_voc_forward_feats");
-    const int halo = halo_units < 0 ? VOC_RECEPTIVE_UNITS : halo_units;
+    const int halo = halo_units < 0 ? voc_receptive_units(v) : halo_units;
     const int span = chunk_units + 2 * halo, hop = v->up_total;
     hipStream_t s = (hipStream_t)stream;
     Arena a(ws, ws_bytes);
@@ -1046,8 +1089,8 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
     Arena a(ws, ws_bytes);
     float* x0 = a.take<float>((size_t)B * c.model_in_dim * U);
     const size_t mx = voc_max_act(v, B, U);
-    const int ns_alloc = v->mrf_streams;
-    const int ns = (v->mrf_auto && (long)B * U > 8192) ? 1 : v->mrf_streams;
+    const int ns = voc_streams(v, B, U);
+    const int ns_alloc = ns;  // (parrot_voc_workspace_bytes reserves exactly these)
     std::unique_lock<std::mutex> side_lock(v->side_mu, std::defer_lock);
     if (ns > 1) side_lock.lock();
     float* P[3];
@@ -1243,10 +1286,11 @@ extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, 
     t->cfg = c;
     t->scheme = default_prec();
     {
-        // flash attention runs on the fp16 split pipe: the default scheme and the reduced-precision modes take it; the exact
-        // (f32) and bf16x6 handles keep the fp32-MFMA cores (fused for T <= 256, three kernels beyond)
+        // flash attention runs on the fp16 split pipe: the default scheme and the fp16 reduced-precision mode take it; the exact
+        // (f32), bf16x6 and bf16 handles keep the fp32-MFMA cores (fused for T <= 256, three kernels beyond)
         static const bool want = [] { const char* e = getenv("PARROT_FLASH_ATTN"); return !e || atoi(e) != 0; }();
-        const bool sch_ok = t->scheme == PARROT_PREC_F16X3 || t->scheme == PARROT_PREC_BF16 || t->scheme == PARROT_PREC_F16;
+        // (attn_flash_kernel is built on the fp16 pipe: a bf16 handle keeps fp32's exponent range by staying on the fp32-MFMA cores)
+        const bool sch_ok = t->scheme == PARROT_PREC_F16X3 || t->scheme == PARROT_PREC_F16;
         auto hd_ok = [&](int layers, int heads) { return layers == 0 || (heads > 0 && c.d_model % heads == 0 && attn_flash_has(c.d_model / heads)); };
         t->flash = want && sch_ok && hd_ok(c.enc_layers, c.enc_heads) && hd_ok(c.dec_layers, c.dec_heads);
     }
@@ -1354,12 +1398,8 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
         p.alpha = (float)std::sqrt(1.0 / (double)hd);
         static const int qt = [] { const char* e = getenv("PARROT_ATTN_QT"); return (e && atoi(e) == 64) ? 64 : 32; }();
         const size_t lds = (size_t)qt * (((T + 31) / 32) * 32 + 1) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)((size_t)64 * (ATTN_TMAX + 1) * sizeof(float))));
-            attr_set = true;
-        }
+        static DynLdsOnce lds_once;
+        HIP_TRY(ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(attn_fused_kernel<128, 64>), (size_t)((size_t)64 * (ATTN_TMAX + 1) * sizeof(float))));
         if (qt == 64) hipLaunchKernelGGL((attn_fused_kernel<128, 64>), dim3((T + 63) / 64, B * H), dim3(256), lds, s, p);
         else hipLaunchKernelGGL((attn_fused_kernel<128, 32>), dim3((T + 31) / 32, B * H), dim3(256), lds, s, p);
         HIP_TRY(hipGetLastError());
@@ -1552,5 +1592,15 @@ static int read_flag(int* err, hipStream_t s, const char* who) {
     }
     return PARROT_OK;
 }
+// The flag without a synchronisation: copy it to dst_dev[0] (device memory) on `stream` and clear it, so the caller can read it
+// with a device-to-host transfer it performs anyway (the shims fetch it together with the TTE's expanded lengths).
+static int status_async(int* err, int32_t* dst_dev, hipStream_t s) {
+    if (!dst_dev) return fail(PARROT_E_INVALID, "status_async: null destination");
+    HIP_TRY(hipMemcpyAsync(dst_dev, err, sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(err, 0, sizeof(int), s));
+    return PARROT_OK;
+}
+extern "C" int parrot_voc_status_async(parrot_voc_t* v, int32_t* dst_dev, void* stream) { return v ? status_async(v->err, dst_dev, (hipStream_t)stream) : PARROT_E_INVALID; }
+extern "C" int parrot_tte_status_async(parrot_tte_t* t, int32_t* dst_dev, void* stream) { return t ? status_async(t->err, dst_dev, (hipStream_t)stream) : PARROT_E_INVALID; }
 extern "C" int parrot_voc_check(parrot_voc_t* v, void* stream) { return v ? read_flag(v->err, (hipStream_t)stream, "vocoder") : PARROT_E_INVALID; }
 extern "C" int parrot_tte_check(parrot_tte_t* t, void* stream) { return t ? read_flag(t->err, (hipStream_t)stream, "tte") : PARROT_E_INVALID; }

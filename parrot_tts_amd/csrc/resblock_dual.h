@@ -28,6 +28,27 @@
 
 namespace parrot {
 
+#ifdef RBD_TRACE
+// experiment builds only (tools/build_exp.sh trace -DRBD_TRACE): shader-clock timestamps of one workgroup's phases
+__device__ unsigned long long g_rbd_trace[8][64];
+#define RBD_MARK()                                                                                  \
+    do {                                                                                            \
+        if (trace_on && lane == 0 && tr_i < 62) g_rbd_trace[wave][tr_i] = __builtin_amdgcn_s_memtime(); \
+        ++tr_i;                                                                                     \
+    } while (0)
+#define RBD_TRACE_INIT()                                                                            \
+    const bool trace_on = p.stagger != 0 && (int)blockIdx.x == (int)gridDim.x / 2;                  \
+    int tr_i = 0;                                                                                   \
+    if (trace_on && lane == 0) {                                                                    \
+        unsigned hwid;                                                                              \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));                          \
+        g_rbd_trace[wave][63] = hwid;                                                               \
+    }
+#else
+#define RBD_MARK() do { } while (0)
+#define RBD_TRACE_INIT() do { } while (0)
+#endif
+
 constexpr int RBD_GUARD = 1024;  // guard bytes either side of a window's operand buffer (max read-ahead 40 columns x 16 B)
 
 // (x0, x1) -> NP packed 16-bit pairs; the fp16 two-piece split takes the fma-mix shortcut
@@ -46,21 +67,21 @@ __device__ __forceinline__ void split_fast(float x0, float x1, unsigned (&q)[SCH
 
 // NCH = channel chunks of 16: 2 -> 32 channels (window 384: four waves side by side), 4 -> 64 channels (window 192: 2 row
 // tiles x 2 column halves) -- per window exactly the tiling of resblock_split_kernel<SCH, NCH>.
-template <class SCH, int NCH>
-__global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSplitParams p) {
+template <class SCH, int NCH, int NWIN>
+__global__ __launch_bounds__(256 * NWIN, NWIN == 1 ? 3 : 1) void resblock_dual_kernel(const ResblockSplitParams p) {
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = 4 / WAVES_M, NTW = 3, W = WAVES_N * NTW * 32;
     constexpr int OCT_BYTES = W * 16, CH_BYTES = 2 * OCT_BYTES, PIECE_BYTES = NCH * CH_BYTES;
     constexpr int WIN_BYTES = NPC * PIECE_BYTES + 2 * RBD_GUARD;
     static_assert(NCH == 2 || NCH == 4, "32 or 64 channels");
     static_assert((NPC - 1) * PIECE_BYTES + (NCH - 1) * CH_BYTES + OCT_BYTES < 65536, "fragment offsets must fit the ds_read immediate");
-    extern __shared__ __attribute__((aligned(16))) char smem_all[];  // 2 x WIN_BYTES
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];  // NWIN x WIN_BYTES
     const int K = p.k;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int win = wave >> 2, w4 = wave & 3;  // window of this wave, wave inside the window
+    const int win = (NWIN == 2) ? wave >> 2 : 0, w4 = wave & 3;  // window of this wave, wave inside the window
     const int wm = w4 / WAVES_N;               // row tile (32 output channels)
     const int wn = w4 % WAVES_N;               // column group (96 columns)
     const int half = lane >> 5;
@@ -69,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
     // two consecutive windows of the launch per workgroup (neighbours in the same row share their halo columns in L2);
     // an odd window count leaves the last workgroup's B without work: it re-computes the last window and stores nothing
     const int total = p.tiles * p.B;
-    const int wid_raw = 2 * (int)blockIdx.x + win;
+    const int wid_raw = NWIN * (int)blockIdx.x + win;
     const bool live = wid_raw < total;
     const int wid = live ? wid_raw : total - 1;
     const int b = wid / p.tiles;
@@ -77,6 +98,8 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
     const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
     const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);  // window not fully inside the row
+    RBD_TRACE_INIT();
+    RBD_MARK();  // 0: start
 
     {   // guard bytes: zero (never NaN patterns from an earlier kernel's LDS contents)
         const int t256 = tid & 255;
@@ -129,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
     }
 
     // B runs one barrier behind A from here on (A converts its first operand while B is still loading)
-    if (win) __syncthreads();
+    if (NWIN == 2 && win) __syncthreads();
 
     const int center = (K - 1) / 2;
     // fragment base address of this lane per tile: column col[nt], octet `half` of chunk 0, piece 0 (unclamped: guard bytes)
@@ -153,16 +176,24 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int set = ch & 1;
+#ifndef EXP_RBD_NO_B
                 if (ch + 1 < NCH) load_b(Bv[set ^ 1], ch + 1, shift16);
                 else load_b(Bv[set ^ 1], 0, shift16 + dil * 16);
+#endif
                 const int nx = (ch + 2 < NCH) ? gbase + (ch + 2) * K + j : n0 + (ch + 2 - NCH) * K;  // two steps ahead
 #pragma unroll
                 for (int t = 0; t < NTERM; ++t) {
+#ifndef EXP_RBD_NO_MFMA
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) acc[nt] = mfma32<SCH>(A[set][SCH::pa(t)], Bv[set][nt][SCH::pb(t)], acc[nt]);
+#endif
+#ifndef EXP_RBD_NO_A
 #pragma unroll
                     for (int pc = 0; pc < NPC; ++pc)
                         if (t == SCH::last_a(pc)) load_a_piece(A[set], pc, nx);
+#else
+                    (void)nx;
+#endif
                 }
             }
             // issue order: one memory instruction in the shadow of each MFMA (see conv_split.h)
@@ -200,6 +231,9 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
         // accumulator tile -> operand buffer: lrelu(c v) = max(c v, c slope v), (mask,) split, half-wave swap, 16-byte stores
         auto write_p = [&](const f32x16 (&v)[NTW], float mul) __attribute__((always_inline)) {
             const float m2 = mul * p.slope;
+#ifdef EXP_RBD_NO_WP
+            if (p.n_conv >= 0) return;
+#endif
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
@@ -225,11 +259,16 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
                         const auto r1 = __builtin_amdgcn_permlane32_swap(qq[0][1][pc], qq[1][1][pc], false, false);
                         *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES) = uint4{r0[0], r1[0], r0[1], r1[1]};
                     }
+                    // (keep the groups apart: interleaving all 48 elements' chains costs more registers than the 168 of three workgroups per CU)
+                    if constexpr (NWIN == 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
+        RBD_MARK();  // 1: before the first conversion
         write_p(R, SCH::XS);  // (out-of-range columns were loaded as zeros)
+        RBD_MARK();  // 2
         __syncthreads();
+        RBD_MARK();  // 3
         for (int m = 0; m < p.n_conv; m += 2) {
             float bv[16];
             // h = conv_d(P) + b1   (accumulator scale s1 = XS * wsc[m])
@@ -240,9 +279,13 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = bv[r] * s1;
             conv(p.dil[m]);
+            RBD_MARK();  // 4 + 8i: conv1 done
             __syncthreads();  // every wave of the window is done reading P (and the other window's role flips)
+            RBD_MARK();  // 5
             write_p(acc, SCH::XS / s1);  // P = split(lrelu(h)), masked
+            RBD_MARK();  // 6
             __syncthreads();
+            RBD_MARK();  // 7
             // R = conv_1(P) + b2 + R: the residual rides in the accumulator (scale s2); R is in scale rs
             bias_rows(p.bias[m + 1], bv);
             const float rr = s2 / rs;
@@ -259,16 +302,20 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
                     else R[nt][r] = acc[nt][r];
                 }
             rs = s2;
+            RBD_MARK();  // 8: conv2 done
             if (m + 2 < p.n_conv) {
                 __syncthreads();
+                RBD_MARK();  // 9
                 write_p(R, SCH::XS / rs);
+                RBD_MARK();  // 10
                 __syncthreads();
+                RBD_MARK();  // 11
             }
         }
     };
     if (edge) pairs(std::true_type{});
     else pairs(std::false_type{});
-    if (!win) __syncthreads();  // A's share of the barrier B spent at the start
+    if (NWIN == 2 && !win) __syncthreads();  // A's share of the barrier B spent at the start
 
     // ---- write the central TT columns (registers -> global, 128-byte runs per row) ---------------------------------
     float* __restrict__ yb = p.y + (size_t)b * C * p.T + (size_t)(32 * wm) * p.T;
@@ -297,8 +344,8 @@ __global__ __launch_bounds__(512, 1) void resblock_dual_kernel(const ResblockSpl
 }
 
 // ---- 16-channel variant (resblock16_split_kernel's tiling: 16x16x32 MFMA, k-step = 16 channels x two taps, window 768) ----
-template <class SCH>
-__global__ __launch_bounds__(512, 1) void resblock16_dual_kernel(const ResblockSplitParams p) {
+template <class SCH, int NWIN>
+__global__ __launch_bounds__(256 * NWIN, NWIN == 1 ? 3 : 1) void resblock16_dual_kernel(const ResblockSplitParams p) {
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16, NT = 12, W = RBS16_W, NP = NT / 2;
     constexpr int OCT_BYTES = W * 16, PIECE_BYTES = 2 * OCT_BYTES;  // [piece][octet][col][8 channels]
@@ -310,12 +357,12 @@ __global__ __launch_bounds__(512, 1) void resblock16_dual_kernel(const ResblockS
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int win = wave >> 2, w4 = wave & 3;
+    const int win = (NWIN == 2) ? wave >> 2 : 0, w4 = wave & 3;
     const int g4 = lane >> 4;  // C/D row group; as an operand lane: channel octet g4 & 1, tap parity g4 >> 1
     const int l15 = lane & 15;
     char* const smem_raw = smem_all + win * WIN_BYTES + RBD_GUARD;
     const int total = p.tiles * p.B;
-    const int wid_raw = 2 * (int)blockIdx.x + win;
+    const int wid_raw = NWIN * (int)blockIdx.x + win;
     const bool live = wid_raw < total;
     const int wid = live ? wid_raw : total - 1;
     const int b = wid / p.tiles;
@@ -323,6 +370,8 @@ __global__ __launch_bounds__(512, 1) void resblock16_dual_kernel(const ResblockS
     const int t_base = tile * p.TT - p.H;
     const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);
+    RBD_TRACE_INIT();
+    RBD_MARK();  // 0: start
     const int col0 = w4 * (NT * 16) + l15;  // this lane's window column in tile 0 (tile nt adds 16 nt)
 
     {   // guard bytes: zero
@@ -362,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void resblock16_dual_kernel(const ResblockS
         load_a_piece(A[1], pc, 1);
     }
 
-    if (win) __syncthreads();  // B runs one barrier behind A
+    if (NWIN == 2 && win) __syncthreads();  // B runs one barrier behind A
 
     const int center = (K - 1) / 2;
     int gstep = 0;
@@ -453,10 +502,14 @@ __global__ __launch_bounds__(512, 1) void resblock16_dual_kernel(const ResblockS
                     const auto r1 = __builtin_amdgcn_permlane16_swap(qq[0][1][pc], qq[1][1][pc], false, false);
                     *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES) = uint4{r0[0], r1[0], r0[1], r1[1]};
                 }
+                if constexpr (NWIN == 1) __builtin_amdgcn_sched_barrier(0);
             }
         };
+        RBD_MARK();  // 1
         write_p(R, SCH::XS);
+        RBD_MARK();  // 2
         __syncthreads();
+        RBD_MARK();  // 3
         for (int m = 0; m < p.n_conv; m += 2) {
             float bv[4];
             const float s1 = SCH::XS * p.wsc[m], s2 = SCH::XS * p.wsc[m + 1];
@@ -467,9 +520,13 @@ __global__ __launch_bounds__(512, 1) void resblock16_dual_kernel(const ResblockS
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[nt][r] = bv[r];
             conv(p.dil[m]);
+            RBD_MARK();  // 4 + 8i
             __syncthreads();
+            RBD_MARK();  // 5
             write_p(acc, SCH::XS / s1);
+            RBD_MARK();  // 6
             __syncthreads();
+            RBD_MARK();  // 7
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + 1][4 * g4 + r] * s2;
 #pragma unroll
@@ -491,16 +548,20 @@ __global__ __launch_bounds__(512, 1) void resblock16_dual_kernel(const ResblockS
                     R[nt][r] = (EDGE && !tk) ? 0.f : v;
                 }
             }
+            RBD_MARK();  // 8
             if (m + 2 < p.n_conv) {
                 __syncthreads();
+                RBD_MARK();  // 9
                 write_p(R, SCH::XS);
+                RBD_MARK();  // 10
                 __syncthreads();
+                RBD_MARK();  // 11
             }
         }
     };
     if (edge) pairs(std::true_type{});
     else pairs(std::false_type{});
-    if (!win) __syncthreads();  // A's share of the barrier B spent at the start
+    if (NWIN == 2 && !win) __syncthreads();  // A's share of the barrier B spent at the start
 
     float* __restrict__ yb = p.y + (size_t)b * C * p.T;
     const bool has_acc = p.epi != EPI_STORE;
@@ -524,21 +585,25 @@ __global__ __launch_bounds__(512, 1) void resblock16_dual_kernel(const ResblockS
     }
 }
 
-template <class SCH>
-inline hipError_t launch_resblock_dual_s(int C, const ResblockSplitParams& p, hipStream_t s) {
-    const size_t lds = 2 * ((size_t)SCH::NP * 2 * RBS_W * 32 + 2 * RBD_GUARD);
-    auto kern = (C == 16) ? resblock16_dual_kernel<SCH> : (C == 64) ? resblock_dual_kernel<SCH, 4> : resblock_dual_kernel<SCH, 2>;
-    static bool attr_set[3] = {false, false, false};
+template <class SCH, int NWIN>
+inline hipError_t launch_resblock_dual_t(int C, const ResblockSplitParams& p, hipStream_t s) {
+    const size_t lds = NWIN * ((size_t)SCH::NP * 2 * RBS_W * 32 + 2 * RBD_GUARD);
+    auto kern = (C == 16) ? resblock16_dual_kernel<SCH, NWIN> : (C == 64) ? resblock_dual_kernel<SCH, 4, NWIN> : resblock_dual_kernel<SCH, 2, NWIN>;
+    static DynLdsOnce lds_once[3];
     const int slot = (C == 16) ? 2 : (C == 64) ? 1 : 0;
-    if (!attr_set[slot]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dyn_lds(lds_once[slot], reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
-        attr_set[slot] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((p.tiles * p.B + 1) / 2), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((p.tiles * p.B + NWIN - 1) / NWIN), dim3(256 * NWIN), lds, s, p);
     return hipGetLastError();
 }
+// nwin = 2: dual-window anti-phase workgroups; nwin = 1: one window per workgroup (three per CU) with the same lean VALU code
+template <class SCH>
+inline hipError_t launch_resblock_dual_s(int C, int nwin, const ResblockSplitParams& p, hipStream_t s) {
+    return nwin == 2 ? launch_resblock_dual_t<SCH, 2>(C, p, s) : launch_resblock_dual_t<SCH, 1>(C, p, s);
+}
 inline bool resblock_dual_has(int scheme, int C) { return scheme == SchF16x3::ID && (C == 16 || C == 32 || C == 64); }
-hipError_t launch_resblock_dual_f16x3(int C, const ResblockSplitParams& p, hipStream_t s);  // csrc/tu_resblock_dual.hip
+hipError_t launch_resblock_dual_f16x3(int C, int nwin, const ResblockSplitParams& p, hipStream_t s);  // csrc/tu_resblock_dual.hip
 
 }  // namespace parrot

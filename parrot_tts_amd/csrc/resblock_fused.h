@@ -332,12 +332,10 @@ inline int resblock_window(int C) { return C <= 16 ? 1024 : 512; }
 inline hipError_t launch_resblock_fused(const ResblockParams& p, hipStream_t s) {
     if (p.C == 16) {
         const size_t lds = (size_t)2 * 16 * (1024 + 2 * RB16_PAD) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fused16_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
+        {
+            hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(resblock_fused16_kernel), (size_t)lds);
             if (e != hipSuccess) return e;
-            attr_set = true;
         }
         hipLaunchKernelGGL(resblock_fused16_kernel, dim3(p.tiles * p.B), dim3(512), lds, s, p);
         return hipGetLastError();

@@ -542,12 +542,11 @@ template <class SCH>
 inline hipError_t launch_resblock_split_s(int C, const ResblockSplitParams& p, hipStream_t s) {
     const size_t lds = (size_t)SCH::NP * 2 * RBS_W * 32;  // the same for every channel count (72 KiB with three pieces)
     auto kern = (C == 16) ? resblock16_split_kernel<SCH> : (C == 64) ? resblock_split_kernel<SCH, 4> : resblock_split_kernel<SCH, 2>;
-    static bool attr_set[3] = {false, false, false};
+    static DynLdsOnce lds_once[3];
     const int slot = (C == 16) ? 0 : (C == 64) ? 2 : 1;
-    if (!attr_set[slot]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dyn_lds(lds_once[slot], reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
-        attr_set[slot] = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
     return hipGetLastError();

@@ -254,12 +254,11 @@ template <class SCH>
 inline hipError_t launch_resblock_split16_s(int C, const ResblockSplitParams& p, hipStream_t s) {
     const size_t lds = (size_t)SCH::NP * (C / 32) * 4 * (C == 32 ? 384 : 192) * 16;
     auto kern = (C == 64) ? resblock_split16_kernel<SCH, 4> : resblock_split16_kernel<SCH, 2>;
-    static bool attr_set[2] = {false, false};
+    static DynLdsOnce lds_once[2];
     const int slot = (C == 64) ? 1 : 0;
-    if (!attr_set[slot]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dyn_lds(lds_once[slot], reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
-        attr_set[slot] = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
     return hipGetLastError();

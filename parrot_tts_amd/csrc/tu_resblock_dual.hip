@@ -2,5 +2,10 @@
 // dual-window anti-phase fused ResBlock pair kernels (resblock_dual.h) for the default scheme.
 #include "resblock_dual.h"
 namespace parrot {
-hipError_t launch_resblock_dual_f16x3(int C, const ResblockSplitParams& p, hipStream_t s) { return launch_resblock_dual_s<SchF16x3>(C, p, s); }
+hipError_t launch_resblock_dual_f16x3(int C, int nwin, const ResblockSplitParams& p, hipStream_t s) { return launch_resblock_dual_s<SchF16x3>(C, nwin, p, s); }
 }  // namespace parrot
+#ifdef RBD_TRACE
+extern "C" int parrot_debug_rbd_trace(unsigned long long* out_host) {
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(parrot::g_rbd_trace), sizeof(unsigned long long) * 8 * 64);
+}
+#endif

@@ -27,7 +27,10 @@ class SynthesisPipeline:
         (defaults to the TTE speaker ids).  Returns wav (B,1,hop*L), n_samples (B,) = hop*emitted ids
         per row (rows shorter than L emit len+1 ids, reference quirk Q2), ids, tgt_mask.  wav[b, :, n_samples[b]:] is
         unspecified (padding)."""
-        r = self.parrot.infer_dense(batch)
+        # the vocoder's device flag of the PREVIOUS call (bad unit id, non-finite waveform: an activation beyond the fp16 split
+        # scheme's range) is read with the TTE's length transfer: a checkpoint that leaves the range fails loudly, by default,
+        # one call late and at no extra synchronisation (`check()` covers the last call)
+        r = self.parrot.infer_dense(batch, status_hooks=(self.generator._status_hook,))
         ids = r["ids"]
         if spkr is None and self.generator.multispkr:
             spkr = batch["speaker"].reshape(-1, 1)
@@ -37,6 +40,12 @@ class SynthesisPipeline:
         # each row is vocoded with its own sequence end, i.e. exactly as the reference would vocode that row's ids alone
         wav = self.generator(code=ids, spkr=spkr, unit_lens=emitted)
         return {"wav": wav, "n_samples": emitted * hop, "ids": ids, "tgt_mask": r["tgt_mask"], "lens": r["lens"]}
+
+    def check(self) -> None:
+        """Synchronise and raise what the device flagged in the calls so far (IndexError: bad ids; FloatingPointError: non-finite
+        logits / waveform).  `__call__` reports the previous call's flags by itself; this covers the last one."""
+        self.parrot.check_outputs()
+        self.generator.check_inputs()
 
     # ---- two-stage software pipeline across batches --------------------------------------------------------------
     # The TTE is ~13 % of a step but made of small, latency-bound launches (64-512 workgroups, one host round trip for
@@ -55,6 +64,8 @@ class SynthesisPipeline:
         done = self._vocode_pending(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(inputs_ready)
+            # (no vocoder status hook here: this TTE runs on a side stream BESIDE the previous batch's vocoder, and the hook's
+            #  read-and-clear of the flag would race with that forward; `check()` covers the pipelined schedule)
             r = self.parrot.infer_dense(batch)  # (its host sync for L waits on the side stream only)
             ids = r["ids"]
             if spkr is None and self.generator.multispkr:

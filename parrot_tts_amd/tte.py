@@ -167,8 +167,20 @@ class Parrot(nn.Module):
         self._handle, self._handle_device = hdl, device
 
     # ---- forward ------------------------------------------------------------------------------
+    @staticmethod
+    def _raise_status(code: int, who: str):
+        """Device status codes (csrc/kernels_misc.h) -> the exceptions the reference raises / this package promises."""
+        if code == 0:
+            return
+        if code == 5:
+            raise FloatingPointError(f"{who}: non-finite output (waveform sample / logits) -- an activation left the range of the fp16 split "
+                                     "scheme (|x| < 8190); use PARROT_PRECISION=bf16x6 or f32 for this checkpoint")
+        raise IndexError(f"{who}: embedding index out of range (code {code})")
+
     @torch.no_grad()
-    def _run(self, batch, want_logits: bool):
+    def _run(self, batch, want_logits: bool, status_hooks=()):
+        """``status_hooks``: callables ``hook(dst_ptr, stream_ptr) -> name`` that enqueue a copy of another handle's device status
+        flag (the vocoder's, see SynthesisPipeline): they ride on the one device-to-host transfer this method performs anyway."""
         phones = batch["phones"]
         require_cuda(phones, "batch['phones']")
         dev = phones.device
@@ -183,7 +195,9 @@ class Parrot(nn.Module):
             speaker = batch["speaker"].to(dev, torch.int64).contiguous()
         log_dur = torch.empty((B, S), dtype=torch.float32, device=dev)
         dur = torch.empty((B, S), dtype=torch.int64, device=dev)
-        lens = torch.empty((B,), dtype=torch.int32, device=dev)
+        # expanded lengths + this handle's status flag + one slot per hook: ONE device-to-host transfer fetches them all
+        status = torch.zeros((B + 1 + len(status_hooks),), dtype=torch.int32, device=dev)
+        lens = status[:B]
         state = torch.empty(lib.parrot_tte_state_bytes(self._handle, B, S), dtype=torch.uint8, device=dev)
         ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, B, S, 0), dtype=torch.uint8, device=dev)
         st = stream_ptr(dev)
@@ -191,8 +205,15 @@ class Parrot(nn.Module):
             try:
                 _lib.check(lib.parrot_tte_encode(self._handle, dptr(phones), dptr(valid), dptr(speaker), B, S, dptr(log_dur), dptr(dur),
                                                  dptr(lens), dptr(state), state.numel(), dptr(ws), ws.numel(), st))
-                lens_h = lens.cpu()  # the one host sync the reference also has (duration.py:10)
-                _lib.check(lib.parrot_tte_check(self._handle, st))
+                _lib.check(lib.parrot_tte_status_async(self._handle, status.data_ptr() + 4 * B, st))
+                names = [hook(status.data_ptr() + 4 * (B + 1 + i), st) for i, hook in enumerate(status_hooks)]
+                status_h = status.cpu()  # the one host sync the reference also has (duration.py:10)
+                lens_h = status_h[:B]
+                # bad phone / speaker ids of THIS encode (the reference's Embedding IndexError), non-finite logits of the previous
+                # decode, and whatever the hooks watch (the previous vocoder forward): raised here, by default, at no extra sync
+                self._raise_status(int(status_h[B]), "tte")
+                for i, nm in enumerate(names):
+                    self._raise_status(int(status_h[B + 1 + i]), nm)
                 L = int(lens_h.max())
                 del ws
                 ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, B, S, L), dtype=torch.uint8, device=dev)
@@ -266,11 +287,11 @@ class Parrot(nn.Module):
         ids, msk = r["ids"].cpu(), r["tgt_mask"].cpu()
         return [c[m].numpy().tolist() for c, m in zip(ids, msk)]
 
-    def infer_dense(self, batch) -> dict:
+    def infer_dense(self, batch, status_hooks=()) -> dict:
         """Batched, device-resident result (ids (B,L), tgt_mask, lens) for pipelines that feed the vocoder
         directly instead of going through Python lists."""
         assert self.training == False  # noqa: E712
-        return self._run(batch, want_logits=False)
+        return self._run(batch, want_logits=False, status_hooks=status_hooks)
 
 
 def lib_n_codes(m: "Parrot") -> int:

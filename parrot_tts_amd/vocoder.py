@@ -297,9 +297,21 @@ class CodeGenerator(nn.Module):
                                      "use PARROT_PRECISION=bf16x6 (fp32's range) for this checkpoint")
         return wav
 
-    # Receptive field of the whole generator, in units either side of an output frame (+-6378 output
-    # samples ~ +-20 units, perturb-one-unit probe): an interior chunk computed with this much context is exact.
-    RECEPTIVE_UNITS = 20
+    def receptive_units(self, device=None) -> int:
+        """Receptive field of the whole generator in units, either side of an output frame, computed by the library from
+        the configuration (interval propagation through conv_post, the MRF stages, the transposed convs and conv_pre): 21 for
+        the shipped config (SURVEY's +-6378 samples leaves out the reach of the transposed convs).  An interior chunk
+        computed with this much real context equals the whole-utterance forward."""
+        dev = device or self._handle_device or next(self.parameters()).device
+        self._current_handle(dev)
+        return int(_lib.lib().parrot_voc_receptive_units(self._handle))
+
+    def _status_hook(self, dst_ptr: int, stream: int) -> str:
+        """Enqueue a copy of this handle's device status flag (bad ids / non-finite waveform of EARLIER forwards) to ``dst_ptr``
+        without synchronising: `Parrot._run` fetches it together with the expanded lengths."""
+        if self._handle is not None:
+            _lib.check(_lib.lib().parrot_voc_status_async(self._handle, dst_ptr, stream))
+        return "vocoder (previous forward)"
 
     @torch.no_grad()
     def stream(self, chunk_units: int = 256, halo_units: Optional[int] = None, unit_lens: Optional[torch.Tensor] = None, **kwargs):
@@ -312,7 +324,7 @@ class CodeGenerator(nn.Module):
         code = kwargs["code"]
         if chunk_units <= 0:
             raise ValueError("chunk_units must be positive")
-        halo = self.RECEPTIVE_UNITS if halo_units is None else int(halo_units)
+        halo = self.receptive_units(code.device) if halo_units is None else int(halo_units)
         U, hop = code.shape[1], self.upsample_factor
         for start in range(0, U, chunk_units):
             stop = min(U, start + chunk_units)
@@ -396,6 +408,7 @@ def generate(h, generator: CodeGenerator, code: dict):
     torch.cuda.synchronize(dev)
     sr = h["sampling_rate"] if isinstance(h, dict) else h.sampling_rate
     rtf = (time.time() - start) / (y.shape[-1] / sr)
+    generator.check_inputs()  # the stream is idle already: a bad id / a non-finite sample fails here, loudly, by default
     return audio16.cpu().numpy(), rtf
 
 

@@ -39,9 +39,11 @@ def _run(dual, path):
     return torch.load(path)
 
 
-def test_dual_window_kernels_are_bit_identical_to_the_one_window_kernels(tmp_path):
-    a = _run(1, str(tmp_path / "dual.pt"))
+@pytest.mark.parametrize("mode", [1, 2])
+def test_dual_window_kernels_are_bit_identical_to_the_one_window_kernels(tmp_path, mode):
+    """PARROT_RB_DUAL=1: lean-VALU kernels, one window per workgroup; =2: dual-window anti-phase workgroups; 0: resblock_split.h."""
+    a = _run(mode, str(tmp_path / "dual.pt"))
     b = _run(0, str(tmp_path / "single.pt"))
     for key in a:
         assert torch.isfinite(a[key]).all()
-        assert torch.equal(a[key], b[key]), f"dual-window waveform differs from the one-window kernels at (B, U) = {key}: max {float((a[key] - b[key]).abs().max())}"
+        assert torch.equal(a[key], b[key]), f"mode {mode} waveform differs from the round-2 kernels at (B, U) = {key}: max {float((a[key] - b[key]).abs().max())}"

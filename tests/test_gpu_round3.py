@@ -1,0 +1,116 @@
+"""GPU tests of the round-3 host-side changes: the receptive field computed from the config (the chunk halo), input validation
+of the native chunked path, and the default-on non-finite guard of the pipeline (flag read with the TTE's length transfer)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import parrot_oracle as O  # noqa: E402
+from parrot_tts_amd import synth  # noqa: E402
+from parrot_tts_amd.pipeline import SynthesisPipeline  # noqa: E402
+from parrot_tts_amd.tte import Parrot  # noqa: E402
+from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _gen(h, sd):
+    g = CodeGenerator(AttrDict(h))
+    g.load_state_dict(sd)
+    return g.eval().to(DEV)
+
+
+def _oracle_receptive_units(h, sd, U=64):
+    """Brute force on the CPU oracle: perturb the embedding of ONE unit in the middle and find the furthest output frame (in
+    units) that moves -- by symmetry of the definition that is the context an output frame needs on either side."""
+    hop = int(np.prod(h["upsample_rates"]))
+    code = torch.zeros(1, U, dtype=torch.int64)
+    spkr = torch.zeros(1, 1, dtype=torch.int64)
+    code2 = code.clone()
+    mid = U // 2
+    code2[0, mid] = 1
+    with torch.no_grad():
+        a = O.code_generator_forward(sd, h, code, spkr)[0, 0]
+        b = O.code_generator_forward(sd, h, code2, spkr)[0, 0]
+    moved = torch.nonzero(a != b).flatten()
+    lo, hi = int(moved.min()) // hop, int(moved.max()) // hop
+    return max(mid - lo, hi - mid)
+
+
+def test_receptive_field_is_computed_from_the_config():
+    """the halo of the chunk-streamed path was a constant 20 units, one short of the shipped config's true
+    one-sided dependence (21).  `parrot_voc_receptive_units` propagates the interval through the layers; the brute-force
+    perturbation of the oracle must not reach further than it says (and reaches exactly that far on both configs)."""
+    h = synth.default_voc_config()
+    g = _gen(h, synth.synth_voc_state_dict(h, seed=1234))
+    assert g.receptive_units() == 21
+    hs = synth.small_voc_config()
+    sds = synth.synth_voc_state_dict(hs, seed=3, scale=1.0)
+    gs = _gen(hs, sds)
+    r_lib, r_oracle = gs.receptive_units(), _oracle_receptive_units(hs, sds)
+    assert r_oracle <= r_lib <= r_oracle + 1, (r_lib, r_oracle)
+    # other upsampling shapes: never smaller than what the oracle shows
+    h2 = synth.small_voc_config()
+    h2["upsample_rates"], h2["upsample_kernel_sizes"] = [4, 2, 2], [8, 4, 4]
+    sd2 = synth.synth_voc_state_dict(h2, seed=4, scale=1.0)
+    g2 = _gen(h2, sd2)
+    assert g2.receptive_units() >= _oracle_receptive_units(h2, sd2)
+
+
+def test_native_chunked_path_validates_its_inputs():
+    """forward_chunked hands raw device pointers to the library: wrong dtypes / counts must raise the
+    same ValueErrors as forward() instead of reading past the buffers."""
+    h = synth.small_voc_config()
+    g = _gen(h, synth.synth_voc_state_dict(h, seed=5))
+    b = synth.synth_voc_batch(3, 40, h, seed=1)
+    code, spkr = b["code"].to(DEV), b["spkr"].to(DEV)
+    ok = g.forward_chunked(chunk_units=16, code=code, spkr=spkr, unit_lens=torch.tensor([40, 30, 7], device=DEV))
+    assert ok.shape == (3, 1, 40 * g.upsample_factor)
+    with pytest.raises(ValueError):
+        g.forward_chunked(chunk_units=16, code=code.to(torch.int32), spkr=spkr)
+    with pytest.raises(ValueError):
+        g.forward_chunked(chunk_units=16, code=code[0], spkr=spkr)
+    with pytest.raises(ValueError):
+        g.forward_chunked(chunk_units=16, code=code, spkr=spkr[:1])
+    with pytest.raises(ValueError):
+        g.forward_chunked(chunk_units=16, code=code, spkr=spkr, unit_lens=torch.tensor([40, 30], device=DEV))
+    with pytest.raises(RuntimeError):  # no CPU fallback
+        g.forward_chunked(chunk_units=16, code=code.cpu(), spkr=spkr)
+
+
+def test_pipeline_fails_loudly_by_default_when_the_waveform_leaves_the_fp16_range(tmp_path):
+    """a checkpoint whose activations leave the fp16 split scheme's range must not go unnoticed by
+    default.  The vocoder's device flag is fetched with the NEXT call's length transfer (no extra sync): the second call raises."""
+    cfg, h = synth.small_tte_config(), synth.small_voc_config()
+    cfg["path"]["root_path"] = str(tmp_path)
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({"a": 0, "b": 1}, f)
+    vocab, n_spk = 30, 2
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=31)
+    for k in list(tsd):  # the small vocoder knows 100 units
+        if k.endswith("head.weight") or k.endswith("head.bias"):
+            tsd[k] = tsd[k].clone()
+            tsd[k][100:] = -10.0 if k.endswith("bias") else 0.0
+    vsd = synth.synth_voc_state_dict(h, seed=3)
+    parrot = Parrot(cfg, vocab, 0)
+    parrot.load_state_dict(tsd)
+    batch = {k: v.to(DEV) for k, v in synth.synth_tte_batch(2, 9, vocab, n_spk, seed=1).items()}
+    good = SynthesisPipeline(parrot.eval().to(DEV), _gen(h, vsd))
+    for _ in range(3):
+        out = good(batch)
+    good.check()
+    assert bool(torch.isfinite(out["wav"]).all())
+    bad_sd = dict(vsd)
+    bad_sd["conv_pre.bias"] = vsd["conv_pre.bias"] + 3.0e4  # far beyond |x| < 8190
+    bad = SynthesisPipeline(parrot, _gen(h, bad_sd))
+    first = bad(batch)  # nothing to report yet: the flag is raised by this very forward
+    assert not bool(torch.isfinite(first["wav"]).all())
+    with pytest.raises(FloatingPointError):
+        bad(batch)
+    bad(batch)  # the flag was cleared when it was reported; this forward raises it again ...
+    with pytest.raises(FloatingPointError):
+        bad.check()  # ... and the explicit check (a sync) covers the last call

@@ -1,11 +1,6 @@
 #!/bin/bash
-# Ablation builds of the library (same sources + -DEXP_* switches) into build_exp/ (git-ignored, shipped by gpurun):
-#   tools/build_exp.sh NO_STORE NO_BARRIER "NO_STORE -DEXP_NO_BARRIER" ...   ->  build_exp/libparrot_<tag>.so
-# select with PARROT_HIP_LIB=build_exp/libparrot_<tag>.so.  Timing experiments only: results are wrong.
+# Experiment builds of the library (same sources + -D switches) into build_exp/ (git-ignored, shipped by gpurun):
+#   tools/build_exp.sh trace -DRBD_TRACE          ->  build_exp/libparrot_trace.so
+# select with PARROT_HIP_LIB=build_exp/libparrot_<tag>.so.  Timing / tracing experiments only.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-mkdir -p "$ROOT/build_exp"
-for spec in "$@"; do
-  tag=$(echo "$spec" | tr -d ' -' | sed 's/DEXP_/_/g')
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DEXP_$spec -o "$ROOT/build_exp/libparrot_$tag.so" "$ROOT/parrot_tts_amd/csrc/parrot_hip.hip" && echo built $tag ) &
-done
-wait
+cd "$ROOT" && mkdir -p build_exp && python -m parrot_tts_amd.build --exp "$@"
