@@ -259,6 +259,22 @@ def main():
         del parrot, gen
         return out
 
+    def product_error_vs_fp64():
+        """What the `dtype` label means numerically: one wide MRF layer (256 -> 256 channels, k = 7, dilation 3) evaluated by the
+        run's scheme and by the exact fp32 MFMA kernel, both against an fp64 evaluation of the same layer (torch CPU)."""
+        import torch.nn.functional as F
+        g = torch.Generator().manual_seed(11)
+        w = torch.randn(256, 256, 7, generator=g) / (256 * 7) ** 0.5
+        bias = torch.randn(256, generator=g) * 0.1
+        x = torch.randn(2, 256, 640, generator=g)
+        ref = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), bias.double(), dilation=3, padding=9)
+        out = {"layer": "Conv1d(256, 256, k=7, dilation=3) on lrelu(x), B=2, T=640; max |y - y_fp64| / max |y_fp64|"}
+        for key, prec_ in ((a.precision, ops.PREC_NAMES[a.precision]), ("f32_exact_mfma", ops.PREC_F32)):
+            plan = ops.ConvPlan(w, bias, dilation=3, padding=9, pre_act=ops.PRE_LRELU, pre_slope=0.1, precision=prec_)
+            y = plan(x.to(dev)).cpu().double()
+            out[key] = float((y - ref).abs().max() / ref.abs().max())
+        return out
+
     def driver_e2e(precision, n_items=256, n_single=32):
         """The shipped vocoder driver end to end (parrot_tts_amd/cli/voc_infer.run_batched): `n_items` utterances of 128-256
         units -> length-bucketed padded batches -> int16 -> pinned host -> peak-normalise -> WAV files on disk, against the same
@@ -298,10 +314,22 @@ def main():
         value = n_samples_step / (ms / 1e3)
         dom = rows[0]
         traffic, traffic_src = pmc_traffic(dom["kernel"])
-        split = "_split" in dom["kernel"]
+        split = "_split" in dom["kernel"] or "resblock" in dom["kernel"]
         n_mfma = SCHEMES[a.precision][1]
         peak = MFMA16_PEAK_TFLOPS / n_mfma if split else FP32_MFMA_PEAK_TFLOPS
+        # what a bare fp16 MFMA stream sustains on THIS box under its power limit (random operands; the constant-operand figure
+        # shows the data dependence), per algorithmic fp32 FMA of the scheme: the practical ceiling next to the 2500 TF spec peak
+        ceil = {}
+        if split:
+            for key, shape, const in (("f16_16x16x32_random", 1, 0), ("f16_32x32x16_random", 0, 0), ("f16_16x16x32_constant", 1, 1)):
+                v_ = C.c_double()
+                _lib.check(lib.parrot_debug_mfma_ceiling(shape, const, C.byref(v_)))
+                ceil[key] = v_.value
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+                "ceiling_probe_tflops": ({"mfma_stream": ceil, "per_fp32_fma": ceil["f16_16x16x32_random"] / n_mfma,
+                                          "frac_of_ceiling": dom["tflops"] / (ceil["f16_16x16x32_random"] / n_mfma),
+                                          "note": "parrot_debug_mfma_ceiling: bare v_mfma_f32_16x16x32_f16 stream, 2 waves/SIMD, measured in this run"}
+                                         if ceil else None),
                 "peak_note": (f"dense 16-bit MFMA peak 2500 TF / {n_mfma} MFMA(s) per algorithmic fp32 FMA ({a.precision}); the kernels are "
                               "clock/power-limited on real data (DESIGN.md section 7)" if split else "fp32 MFMA peak"),
                 "frac": dom["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": dom["avg_us"],
@@ -309,7 +337,10 @@ def main():
         res = {
             "metric": "audio samples/sec (16 kHz; see config.note) + RTF, 256-unit batch-64 per GPU",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f16x3": "f32 (f16x3 split products)", "bf16x6": "f32 (bf16x6 split products)", "f32": "f32", "bf16": "bf16 products, f32 accumulate",
+                      "f16": "f16 products, f32 accumulate"}[a.precision],
+            "data": "synthetic",
             "precision": {"f16x3": "fp32 data/accumulate; products of layers with >=16 channels evaluated as 3 fp16 MFMAs on 2-way fp16 splits "
                                    "of both (power-of-two pre-scaled) fp32 operands: fp32-class error, same parity tolerances; other layers exact fp32 MFMA",
                           "bf16x6": "fp32 data/accumulate; products of layers with >=16 channels evaluated as 6 bf16 MFMAs on 3-way bf16 splits of "
@@ -325,6 +356,7 @@ def main():
                        "parallelism": f"dp{world} (batch shard, RCCL waveform gather)",
                        "weights": "seeded synthetic, reference checkpoint layouts (TTE seed 42 forced duration 4; vocoder seed 1234)",
                        "note": "reference vocoder is 16 kHz / 320 samples per unit (utils/vocoder/config.json:24,32), not 22.05 kHz"},
+            "err_vs_fp64": product_error_vs_fp64(),
             "roofline": roof,
             # the waveform gather's share of a step (max over ranks, CUDA events around the collective; 0 at N = 1) and what the
             # process group really is, so a scaling curve can be decomposed into compute and collective

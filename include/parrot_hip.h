@@ -103,6 +103,10 @@ int parrot_conv_num_tile_cfgs(void);
  * {launches, total ms, algorithmic FLOPs, algorithmic bytes} for n_cfg configurations.         */
 /* dst[i] = src[i], 4 bytes per lane: known-byte-count kernel for calibrating the HBM PMC counters. */
 int parrot_debug_copy(const float* src, float* dst, size_t n, void* stream);
+/* Measurement aid (bench.py `roofline.ceiling_probe_tflops`): the rate a bare fp16 MFMA stream sustains on this device under
+ * its power limit -- shape 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16; random operands (constant_data = 0) or one
+ * constant (1); two waves per SIMD, ~20-40 ms.  Synchronises the device.  TFLOP/s of 16-bit MFMA work in *tflops_out. */
+int parrot_debug_mfma_ceiling(int32_t shape, int32_t constant_data, double* tflops_out);
 int parrot_prof_begin(void);
 int parrot_prof_end(double* out, int32_t n_cfg);
 

@@ -1577,6 +1577,71 @@ extern "C" int parrot_debug_copy(const float* src, float* dst, size_t n, void* s
     return PARROT_OK;
 }
 
+// Sustained rate of a bare 16-bit MFMA stream on THIS device under its power limit (tools/probes/mfma_power.hip as a library
+// call, so bench.py can put the ceiling next to the kernels' rates): 2 waves per SIMD, 24 / 48 MFMAs per loop iteration on four /
+// eight independent accumulators, random fp16 operands with exponents near 1 (or one constant), ~20-40 ms of work.
+template <int SHAPE>
+static __global__ __launch_bounds__(256) void mfma_ceiling_kernel(const s16x8* in, float* out, int iters) {
+    s16x8 a[6], b[6];
+    for (int i = 0; i < 6; ++i) { a[i] = in[threadIdx.x % 64 + 64 * i]; b[i] = in[threadIdx.x % 64 + 64 * (i + 6)]; }
+    float sum = 0.f;
+    if (SHAPE == 0) {  // v_mfma_f32_32x32x16_f16
+        f32x16 acc[4];
+        for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int g = 0; g < 24; ++g)
+                acc[g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[(g >> 2) % 6]), __builtin_bit_cast(f16x8, b[g % 6]), acc[g & 3], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) sum += acc[t][r];
+    } else {  // v_mfma_f32_16x16x32_f16
+        f32x4 acc[8];
+        for (int t = 0; t < 8; ++t) for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int g = 0; g < 48; ++g)
+                acc[g & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(g >> 3) % 6]), __builtin_bit_cast(f16x8, b[g % 6]), acc[g & 7], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) for (int r = 0; r < 4; ++r) sum += acc[t][r];
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+extern "C" int parrot_debug_mfma_ceiling(int32_t shape, int32_t constant_data, double* tflops_out) {
+    if (!tflops_out || shape < 0 || shape > 1) return fail(PARROT_E_INVALID, "mfma_ceiling: shape 0 (32x32x16) or 1 (16x16x32)");
+    query_device();
+    s16x8* in = nullptr;
+    float* out = nullptr;
+    const int grid = g_num_cus * 2, iters = 20000;
+    std::vector<uint16_t> h(64 * 12 * 8);
+    unsigned st = 12345u;
+    for (auto& v : h) {
+        st = st * 1664525u + 1013904223u;
+        v = constant_data ? 0x3c00 : (uint16_t)(((st >> 16) & 0x83ff) | (0x3800 + ((st >> 9) & 0x400)));
+    }
+    HIP_TRY(hipMalloc((void**)&in, h.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void**)&out, (size_t)grid * 256 * sizeof(float)));
+    HIP_TRY(hipMemcpy(in, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    auto run = [&](int n) {
+        if (shape == 0) hipLaunchKernelGGL(mfma_ceiling_kernel<0>, dim3(grid), dim3(256), 0, nullptr, in, out, n);
+        else hipLaunchKernelGGL(mfma_ceiling_kernel<1>, dim3(grid), dim3(256), 0, nullptr, in, out, n);
+    };
+    run(2000);  // warm-up: lets the clock settle under load
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    run(iters);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *tflops_out = (double)grid * 4 * iters * 24 * 32768.0 / ms / 1e9;  // (48 x 16384 flops per iteration for the 16x16x32 shape: the same)
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(in);
+    (void)hipFree(out);
+    return PARROT_OK;
+}
+
 // device-side input-range flag (bad unit / speaker / phone ids <-> the reference's Embedding IndexError).
 // Synchronises the stream; returns 0 or PARROT_E_RANGE and clears the flag.
 static int read_flag(int* err, hipStream_t s, const char* who) {
