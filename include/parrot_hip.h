@@ -186,6 +186,10 @@ int parrot_voc_status_async(parrot_voc_t*, int32_t* dst_dev, void* stream);
  * propagation through conv_post, the MRF stages, the transposed convs of reference utils/vocoder/models.py:80-83 and conv_pre):
  * 21 for the shipped config.  The default halo of parrot_voc_forward_chunked. */
 int parrot_voc_receptive_units(const parrot_voc_t*);
+/* Waveform samples of an utterance of U units: U * prod(upsample_rates) for the shipped configs; a stage with odd
+ * upsample_kernel_size - upsample_rate adds one sample (ConvTranspose1d then yields T u + 1, models.py:80-83): wav_out of
+ * parrot_voc_forward holds B rows of parrot_voc_out_len(U) samples, and a row of n units has parrot_voc_out_len(n) real ones. */
+int64_t parrot_voc_out_len(const parrot_voc_t*, int32_t U);
 /* wav (n) fp32 -> int16 as `(x*32768).astype('int16')` does (utils/vocoder/inference.py:71-73) */
 int parrot_wav_to_int16(const float* wav, int16_t* out, size_t n, void* stream);
 

@@ -196,8 +196,9 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 def resblock1(w, p, x, k, dilations):
-    """utils/vocoder/models.py:31-38."""
-    for m, d in enumerate(dilations):
+    """utils/vocoder/models.py:31-38; the constructor (:17-22) reads dilation[0], [1], [2] literally: exactly three pairs,
+    IndexError for a shorter list, further entries ignored."""
+    for m, d in enumerate((dilations[0], dilations[1], dilations[2])):
         xt = F.leaky_relu(x, LRELU_SLOPE)
         xt = F.conv1d(xt, w[p + f"convs1.{m}.weight"], w[p + f"convs1.{m}.bias"], padding=get_padding(k, d), dilation=d)
         xt = F.leaky_relu(xt, LRELU_SLOPE)
@@ -207,8 +208,8 @@ def resblock1(w, p, x, k, dilations):
 
 
 def resblock2(w, p, x, k, dilations):
-    """utils/vocoder/models.py:58-62."""
-    for m, d in enumerate(dilations):
+    """utils/vocoder/models.py:58-62; the constructor (:51-54) reads dilation[0], [1]: exactly two convs."""
+    for m, d in enumerate((dilations[0], dilations[1])):
         xt = F.leaky_relu(x, LRELU_SLOPE)
         xt = F.conv1d(xt, w[p + f"convs.{m}.weight"], w[p + f"convs.{m}.bias"], padding=get_padding(k, d), dilation=d)
         x = xt + x

@@ -88,6 +88,7 @@ SIGNATURES = {
     "parrot_voc_check": (C.c_int, [vp, vp]),
     "parrot_voc_status_async": (C.c_int, [vp, vp, vp]),
     "parrot_voc_receptive_units": (C.c_int, [vp]),
+    "parrot_voc_out_len": (C.c_int64, [vp, i32]),
     "parrot_wav_to_int16": (C.c_int, [vp, vp, sz, vp]),
     "parrot_tte_create": (C.c_int, [C.POINTER(vp), C.POINTER(TteCfg), C.POINTER(TteWeights)]),
     "parrot_tte_destroy": (None, [vp]),

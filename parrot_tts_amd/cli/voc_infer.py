@@ -90,7 +90,7 @@ def run_batched(gen, rows, dev, sampling_rate, max_rows=64, max_units=16384, wri
         ready.synchronize()  # the D2H copy of this batch (a CUDA event: no device-wide sync)
         pcm = pcm_host.numpy()
         for r, i in enumerate(idx):
-            audio = peak_normalize(pcm[r, : lens[r] * hop].astype(np.float32))
+            audio = peak_normalize(pcm[r, : gen.out_samples(lens[r])].astype(np.float32))
             if write_wavs:
                 write(rows[i][2], sampling_rate, audio)
         return len(idx)

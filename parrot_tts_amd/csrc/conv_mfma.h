@@ -27,6 +27,11 @@
 
 namespace parrot {
 
+// Samples (at the current layer) of a batch row that holds n real units: n * mul + add for n > 0 -- `add` is what the
+// upsampling stages with odd kernel_size - rate contribute (ConvTranspose1d then yields T u + 1 samples, reference
+// utils/vocoder/models.py:80-83) -- and 0 for an empty row.
+__host__ __device__ __forceinline__ int row_true_len(int n, int mul, int add) { return n > 0 ? n * mul + add : 0; }
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember it per (kernel instantiation, device), not per
 // process -- a second device in the same process would otherwise launch with the 64 KiB default and fail.
 struct DynLdsOnce {
@@ -82,6 +87,7 @@ struct ConvParams {
     int u_inv16;         // ceil(65536 / u)
     const int32_t* row_len;  // optional per-batch-row true length (in base units); input positions >= row_len[b]*row_len_mul
     int row_len_mul;         // read as zero: each row then sees its OWN sequence edge (ragged batches); null = Tin for all
+    int row_len_add;         // true length of a row of n > 0 units at this layer = n * row_len_mul + row_len_add (odd k - u upsampling stages add samples)
     int fold_res;            // 1: the residual tile initialises the accumulator (prologue latency hiding); 0: added once in the
                              // epilogue -- what the reference computes (conv, THEN + res): when |res| >> |conv sum| (the TTE's residual
                              // stream) folding makes every accumulation step round at ulp(|res|) instead of ulp(|sum|)
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_mfma_kernel(
     const int tn = blockIdx.x - b * p.tiles_n;
     const int t0 = tn * BN;
     const int W = BN + (p.k - 1) * p.dil;  // live slab width (<= RS, checked on the host)
-    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;  // this row's true input length
+    const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;  // this row's true input length
     const int grp = (p.groups > 1) ? (blockIdx.y * BM) / p.Mg : 0;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride + (size_t)grp * p.Cin * p.Tin;
 

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma16_kernel(const ConvParams
     const int tn = blockIdx.x - b * p.tiles_n;
     const int t0 = tn * BN;
     const int W = BN + (p.k - 1) * p.dil;
-    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;
+    const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride;
 
     float stage[ROWS_PW][COLS_IT];

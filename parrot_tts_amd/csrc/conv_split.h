@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
     const int b = tile_id / p.tiles_n;
     const int tn = tile_id - b * p.tiles_n;
     const int t0 = tn * BN;
-    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;  // this row's true input length
+    const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;  // this row's true input length
     const int W = BN + (p.k - 1) * p.dil;  // columns of the slab this layer can reach
     const int grp = (p.groups > 1) ? (mblock * BM) / p.Mg : 0;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride + (size_t)grp * p.Cin * p.Tin;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void conv_split16_kernel(
     const int b = tile_id / p.tiles_n;
     const int tn0 = tile_id - b * p.tiles_n;
     const int t0 = tn0 * BN;
-    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;
+    const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;
     const int W = BN + (K - 1) * p.dil;
     const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride;
 

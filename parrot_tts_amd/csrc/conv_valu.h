@@ -18,6 +18,7 @@ struct ConvValuParams {
     int act;             // ACT_NONE / ACT_TANH
     const int32_t* row_len;
     int row_len_mul;
+    int row_len_add;         // true length of a row of n > 0 units at this layer = n * row_len_mul + row_len_add (odd k - u upsampling stages add samples)
     int* err;            // optional device flag: set to 5 when a tanh layer's pre-activation is NaN / inf (it reached the waveform)
 };
 
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void conv1_valu_kernel(const ConvValuParams p)
     constexpr int NV = 4 + K - 1;
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;
+    const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;
     const __amdgpu_buffer_rsrc_t xr = valu_row_rsrc(p.x + (size_t)b * p.Cin * p.Tin);
     int voff[NV];
 #pragma unroll
@@ -75,7 +76,7 @@ static __global__ __launch_bounds__(256) void conv1_valu7_vec_kernel(const ConvV
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;
+    const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;
     const __amdgpu_buffer_rsrc_t xr = valu_row_rsrc(p.x + (size_t)b * p.Cin * p.Tin);
     int voff[3];
 #pragma unroll
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void convt_valu_kernel(const ConvValuParams p)
     constexpr int DLO = -((K - 1 - PAD + U - 1) / U), DHI = (U - 1 + PAD) / U, ND = DHI - DLO + 1;  // input offsets used
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
-    const int Tlim = p.row_len ? min(p.Tin, p.row_len[b] * p.row_len_mul) : p.Tin;
+    const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;
     const __amdgpu_buffer_rsrc_t xr = valu_row_rsrc(p.x + (size_t)b * p.Cin * p.Tin);
     int voff[ND];
 #pragma unroll

@@ -476,7 +476,7 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
 // x_bstride / y_bstride / res_bstride in elements; <= 0 means dense.
 static int conv_launch(const parrot_conv* c, const float* x, const float* res, float* y, int B, int Tin, int epi, float div,
                        long x_bstride, long y_bstride, long res_bstride, hipStream_t s, const int32_t* row_len = nullptr,
-                       int row_len_mul = 1) {
+                       int row_len_mul = 1, int row_len_add = 0) {
     if (B <= 0 || Tin <= 0) return fail(PARROT_E_INVALID, "conv_run: empty batch or sequence");
     const int Tout = c->out_len(Tin);
     if (Tout <= 0) return fail(PARROT_E_INVALID, "conv_run: sequence shorter than the kernel");
@@ -486,7 +486,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         q.B = B; q.Cin = c->d.c_in; q.Tin = Tin; q.Tout = Tout;
         q.slope = c->d.pre_act == PRE_LRELU ? c->d.pre_slope : 1.f;
         q.act = c->d.act;
-        q.row_len = row_len; q.row_len_mul = row_len_mul;
+        q.row_len = row_len; q.row_len_mul = row_len_mul; q.row_len_add = row_len_add;
         q.err = c->err_flag;
         ProfRec rec{};
         const double macs = (double)B * c->d.c_out * c->d.c_in * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
@@ -510,7 +510,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.pre = c->d.pre_act; p.pre_slope = c->d.pre_slope; p.act = c->d.act;
     p.epi = epi; p.div = div; p.u = c->u; p.u_inv16 = (65536 + c->u - 1) / c->u;
     p.groups = c->groups; p.Mg = c->Mg;
-    p.row_len = row_len; p.row_len_mul = row_len_mul;
+    p.row_len = row_len; p.row_len_mul = row_len_mul; p.row_len_add = row_len_add;
     p.acc_scale = p.out_scale = 1.f;
     p.fold_res = c->late_res ? 0 : 1;
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
@@ -616,6 +616,7 @@ struct parrot_voc {
     std::vector<int> rb_kind;          // per (stage, kernel): 0 = resblock_split.h kernels, 1 = resblock_split16_kernel
     std::vector<size_t> rb_conv_halves;  // 16-bit words per conv in that stream
     int up_total = 1;
+    bool odd_stage = false;            // some stage has odd kernel_size - rate: T_out = T u + 1 there (no constant hop)
     int scheme = 0;                    // PARROT_PREC_* captured at create (immutable afterwards)
     int fused = 2;                     // fused-ResBlock mode captured at create
     // MRF branch concurrency: the n_kernels ResBlocks of a stage are independent chains until the final sum, so each runs
@@ -689,11 +690,13 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
             for (int j = 0; j < v->mrf_streams; ++j) HIP_TRY(hipEventCreateWithFlags(&v->ev_last[j], hipEventDisableTiming));
         }
     }
-    // every upsampling stage must yield exactly T*u samples (k - u even: true for all HiFi-GAN configs): the workspace,
-    // the waveform buffer and the ragged-row bookkeeping are sized on that (the reference would return T*u + 1 otherwise)
+    // ConvTranspose1d(k, stride u, padding (k - u) // 2) (models.py:80-83) yields T u samples for even k - u (every shipped
+    // config) and T u + 1 for odd k - u: lengths are taken from the convs' own out_len chain (voc_out_len), ragged rows carry
+    // the extra samples as `row_len_add`.  k < u would mean a negative padding, which torch rejects too.
     for (int i = 0; i < cfg->n_stages; ++i) {
         const int u = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
-        if (u <= 0 || k < u || ((k - u) & 1)) return fail(PARROT_E_UNSUPPORTED, "voc_create: upsample_kernel_size - upsample_rate must be even and >= 0");
+        if (u <= 0 || k < u) return fail(PARROT_E_UNSUPPORTED, "voc_create: upsample_kernel_size must be >= upsample_rate (negative padding)");
+        if ((k - u) & 1) v->odd_stage = true;
     }
     TRY(upload(&v->dict, w->dict, (size_t)cfg->num_embeddings * cfg->embedding_dim));
     if (cfg->multispkr) {
@@ -828,13 +831,20 @@ extern "C" void parrot_voc_destroy(parrot_voc_t* v) { delete v; }
 
 static size_t voc_max_act(const parrot_voc* v, int B, int U) {
     size_t mx = (size_t)B * v->cfg.upsample_initial_channel * U;
-    size_t T = U;
+    int T = U;
     for (int i = 0; i < v->cfg.n_stages; ++i) {
-        T *= v->cfg.upsample_rates[i];
-        mx = std::max(mx, (size_t)B * v->chan(i) * T);
+        T = v->ups[i]->out_len(T);
+        mx = std::max(mx, (size_t)B * v->chan(i) * (size_t)T);
     }
     return mx;
 }
+// waveform samples of an utterance of U units: the transposed convs' out_len chain (U * hop unless a stage has odd k - u)
+static long voc_out_len(const parrot_voc* v, int U) {
+    long T = U;
+    for (int i = 0; i < v->cfg.n_stages; ++i) T = v->ups[i]->out_len((int)T);
+    return T;
+}
+extern "C" int64_t parrot_voc_out_len(const parrot_voc_t* v, int32_t U) { return (v && U > 0) ? voc_out_len(v, U) : 0; }
 
 // One fused launch for ResBlock (stage i, kernel j) when the stage is narrow enough to live in LDS.
 // Fused whole-ResBlock kernels (resblock_fused.h): mode 0 off, 1 every eligible stage (16 and 32 channels), 2 only the
@@ -865,7 +875,7 @@ static bool resblock_fusable(const parrot_voc* v, int stage, int j) {
     return resblock_window(C) - 2 * H >= 128;
 }
 static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, int B, int T, int epi, float div,
-                                 hipStream_t s, const int32_t* row_len, int row_len_mul, hipEvent_t before_last = nullptr) {
+                                 hipStream_t s, const int32_t* row_len, int row_len_mul, int row_len_add, hipEvent_t before_last = nullptr) {
     const parrot_voc_cfg& c = v->cfg;
     const int per_rb = (c.resblock_type == 1 ? 2 : 1) * c.n_dil;
     const int base = (stage * c.n_kernels + j) * per_rb;
@@ -874,7 +884,7 @@ static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const fl
     p.n_conv = per_rb; p.type = c.resblock_type;
     p.k = c.resblock_kernel_sizes[j]; p.C = v->chan(stage); p.T = T; p.B = B;
     p.epi = epi; p.div = div; p.slope = 0.1f;
-    p.row_len = row_len; p.row_len_mul = row_len_mul;
+    p.row_len = row_len; p.row_len_mul = row_len_mul; p.row_len_add = row_len_add;
     int H = 0;
     double macs = 0;
     for (int q = 0; q < per_rb; ++q) {
@@ -902,7 +912,8 @@ static int rbs_hmax() {
     return h;
 }
 static int resblock_split_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, float* tmp_a, float* tmp_b, int B, int T,
-                                 int epi, float div, hipStream_t s, const int32_t* row_len, int row_len_mul, hipEvent_t before_last = nullptr) {
+                                 int epi, float div, hipStream_t s, const int32_t* row_len, int row_len_mul, int row_len_add,
+                                 hipEvent_t before_last = nullptr) {
     const parrot_voc_cfg& c = v->cfg;
     const int per_rb = 2 * c.n_dil, k = c.resblock_kernel_sizes[j], C = v->chan(stage);
     const int base = (stage * c.n_kernels + j) * per_rb;
@@ -936,7 +947,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         p.tiles = (T + p.TT - 1) / p.TT;
         p.epi = last ? epi : EPI_STORE;
         p.div = div; p.slope = 0.1f;
-        p.row_len = row_len; p.row_len_mul = row_len_mul;
+        p.row_len = row_len; p.row_len_mul = row_len_mul; p.row_len_add = row_len_add;
         {
             static const int stag = [] { const char* e = getenv("PARROT_STAGGER"); return e ? atoi(e) : 0; }();
             static const int stag16 = [] { const char* e = getenv("PARROT_STAGGER16"); return e ? atoi(e) : -1; }();
@@ -1049,6 +1060,8 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
     if (B <= 0 || U <= 0 || chunk_units <= 0) return fail(PARROT_E_INVALID, "voc_forward_chunked: empty batch or chunk");
     if (v->cfg.model_in_dim != v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1))
         return fail(PARROT_E_UNSUPPORTED, "voc_forward_chunked: models with extra conditioning streams go through parrot_voc_forward_feats");
+    if (v->odd_stage)
+        return fail(PARROT_E_UNSUPPORTED, "voc_forward_chunked: a stage with odd upsample_kernel_size - upsample_rate has no constant samples-per-unit hop to cut chunks on");
     const int halo = halo_units < 0 ? voc_receptive_units(v) : halo_units;
     const int span = chunk_units + 2 * halo, hop = v->up_total;
     hipStream_t s = (hipStream_t)stream;
@@ -1118,8 +1131,8 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
     int ia = 0;
     // unit_lens (optional): per-row number of real units; every layer then applies ITS zero padding at the row's own
     // end (row_len * samples-per-unit so far), so a padded batch row equals the reference's B=1 run of that utterance
-    int mul = 1;
-    TRY(conv_launch(v->conv_pre.get(), x0, nullptr, P[ia], B, U, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
+    int mul = 1, add = 0;  // a row of n units holds n * mul + add samples at the current layer
+    TRY(conv_launch(v->conv_pre.get(), x0, nullptr, P[ia], B, U, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul, add));
     TRY(snap(0, P[ia], (size_t)B * c.upsample_initial_channel * U));
     int T = U;
     const int nk = c.n_kernels, nd = c.n_dil;
@@ -1128,9 +1141,10 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         float* A = P[ia];
         float* X = P[(ia + 1) % 3];
         float* XS = P[(ia + 2) % 3];
-        TRY(conv_launch(v->ups[i].get(), A, nullptr, X, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
+        TRY(conv_launch(v->ups[i].get(), A, nullptr, X, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul, add));
         T = v->ups[i]->out_len(T);
         mul *= c.upsample_rates[i];
+        add = add * c.upsample_rates[i] + ((c.upsample_kernel_sizes[i] - c.upsample_rates[i]) & 1);  // out_len(n mul + add)
         const size_t n_act = (size_t)B * v->chan(i) * T;
         TRY(snap(1 + 2 * i, X, n_act));
         if (ns > 1) {  // fork: the side streams see the upsampled stage input
@@ -1150,20 +1164,20 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
             // (the fused kernels address a batch row with 32-bit byte offsets: rows of 2 GiB and more go layer by layer)
             if (v->fused != 0 && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
-                TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, sj, unit_lens, mul, order));
+                TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, sj, unit_lens, mul, add, order));
             } else if (resblock_fusable(v, i, j)) {
-                TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, sj, unit_lens, mul, order));
+                TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, sj, unit_lens, mul, add, order));
             } else {
                 for (int m = 0; m < nd; ++m) {
                     const bool last = (m == nd - 1);
                     float* dst = last ? XS : ((m & 1) ? RB : RA);
                     if (c.resblock_type == 1)
-                        TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, sj, unit_lens, mul));
+                        TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, sj, unit_lens, mul, add));
                     if (last && order) HIP_TRY(hipStreamWaitEvent(sj, order, 0));
                     if (c.resblock_type == 1)
-                        TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul));
+                        TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul, add));
                     else
-                        TRY(conv_launch(v->rb[base + m].get(), r, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul));
+                        TRY(conv_launch(v->rb[base + m].get(), r, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul, add));
                     r = dst;
                 }
             }
@@ -1174,7 +1188,7 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         TRY(snap(2 + 2 * i, XS, n_act));
         ia = (ia + 2) % 3;
     }
-    TRY(conv_launch(v->conv_post.get(), P[ia], nullptr, wav_out, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul));
+    TRY(conv_launch(v->conv_post.get(), P[ia], nullptr, wav_out, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul, add));
     return PARROT_OK;
 }
 

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256 * NWIN, NWIN == 1 ? 3 : 1) void resblock_dual_k
     const int b = wid / p.tiles;
     const int tile = wid - b * p.tiles;
     const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
-    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
+    const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);  // window not fully inside the row
     RBD_TRACE_INIT();
     RBD_MARK();  // 0: start
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256 * NWIN, NWIN == 1 ? 3 : 1) void resblock16_dual
     const int b = wid / p.tiles;
     const int tile = wid - b * p.tiles;
     const int t_base = tile * p.TT - p.H;
-    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
+    const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);
     RBD_TRACE_INIT();
     RBD_MARK();  // 0: start

@@ -41,6 +41,7 @@ struct ResblockParams {
     float slope;      // leaky-relu slope (0.1)
     const int32_t* row_len;  // optional per-row true length in base units (x row_len_mul = samples at this stage)
     int row_len_mul;
+    int row_len_add;         // true length of a row of n > 0 units at this layer = n * row_len_mul + row_len_add (odd k - u upsampling stages add samples)
 };
 
 template <int NTW>
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(512, 1) void resblock_fused_kernel(const ResblockPa
     const int b = blockIdx.x / p.tiles;
     const int tile = blockIdx.x - b * p.tiles;
     const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
-    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;  // this row's true length
+    const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;  // this row's true length
     const int C = p.C;
     const int nchunks = (C + 15) / 16;
 
@@ -202,7 +203,7 @@ static __global__ __launch_bounds__(512, 1) void resblock_fused16_kernel(const R
     const int b = blockIdx.x / p.tiles;
     const int tile = blockIdx.x - b * p.tiles;
     const int t_base = tile * p.TT - p.H;
-    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
+    const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     constexpr int C = 16;
 
     float* R = smem;

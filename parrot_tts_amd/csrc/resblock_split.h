@@ -50,6 +50,7 @@ struct ResblockSplitParams {
     float slope;
     const int32_t* row_len;
     int row_len_mul;
+    int row_len_add;         // true length of a row of n > 0 units at this layer = n * row_len_mul + row_len_add (odd k - u upsampling stages add samples)
     int stagger;              // phase stagger of co-resident workgroups, in units of 64 clocks per wave slot (0 = off)
     int first_round;          // workgroups of the launch's first round (CUs x workgroups per CU): only they are delayed
 };
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kern
     const int b = blockIdx.x / p.tiles;
     const int tile = blockIdx.x - b * p.tiles;
     const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
-    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
+    const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);  // window not fully inside the row
     phase_stagger(p.stagger, p.first_round);
 
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
     const int b = blockIdx.x / p.tiles;
     const int tile = blockIdx.x - b * p.tiles;
     const int t_base = tile * p.TT - p.H;
-    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
+    const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);
     const int col0 = wave * (NT * 16) + l15;  // this lane's window column in tile 0 (tile nt adds 16 nt)
     phase_stagger(p.stagger, p.first_round);

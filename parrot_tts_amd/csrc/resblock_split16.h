@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void resblock_split16_kernel(const Resblock
     const int b = blockIdx.x / p.tiles;
     const int tile = blockIdx.x - b * p.tiles;
     const int t_base = tile * p.TT - p.H;
-    const int Tlim = p.row_len ? min(p.T, p.row_len[b] * p.row_len_mul) : p.T;
+    const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);
     const int col0 = wave * (NT * 16) + l15;  // this lane's window column in tile 0 (tile tn adds 16 tn)
 

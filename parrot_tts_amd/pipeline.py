@@ -39,7 +39,7 @@ class SynthesisPipeline:
         emitted = torch.clamp(r["lens"].to(torch.int64) + 1, max=L)  # ids per row as Parrot.infer returns them (Q2)
         # each row is vocoded with its own sequence end, i.e. exactly as the reference would vocode that row's ids alone
         wav = self.generator(code=ids, spkr=spkr, unit_lens=emitted)
-        return {"wav": wav, "n_samples": emitted * hop, "ids": ids, "tgt_mask": r["tgt_mask"], "lens": r["lens"]}
+        return {"wav": wav, "n_samples": self.generator.out_samples(emitted), "ids": ids, "tgt_mask": r["tgt_mask"], "lens": r["lens"]}
 
     def check(self) -> None:
         """Synchronise and raise what the device flagged in the calls so far (IndexError: bad ids; FloatingPointError: non-finite
@@ -89,5 +89,5 @@ class SynthesisPipeline:
         for t in (p["ids"], p["emitted_dev"], p["tgt_mask"]) + ((p["spkr"],) if p["spkr"] is not None else ()):
             t.record_stream(main)  # allocated on the side stream, consumed here
         wav = self.generator(code=p["ids"], spkr=p["spkr"], unit_lens=p["emitted_dev"])
-        return {"wav": wav, "n_samples": p["emitted"] * self.generator.upsample_factor, "ids": p["ids"], "tgt_mask": p["tgt_mask"],
+        return {"wav": wav, "n_samples": self.generator.out_samples(p["emitted"]), "ids": p["ids"], "tgt_mask": p["tgt_mask"],
                 "lens": p["lens"]}

@@ -79,6 +79,16 @@ def small_voc_config() -> dict:
     return h
 
 
+def corner_voc_config() -> dict:
+    """Config corners the reference accepts: odd ``upsample_kernel_size - upsample_rate`` (ConvTranspose1d then
+    yields T u + 1 samples, reference utils/vocoder/models.py:80-83) and dilation lists of different lengths per kernel size
+    (ResBlock1 reads the first three entries only, models.py:17-22).  Golden: tests/golden/voc_small_corners.npz."""
+    h = small_voc_config()
+    h["upsample_rates"], h["upsample_kernel_sizes"] = [4, 2, 2], [9, 4, 5]       # k - u = 5, 2, 3: two odd stages
+    h["resblock_dilation_sizes"] = [[1, 2, 3], [1, 3, 5, 7], [2, 1, 4, 9, 11]]    # entries beyond the third are never read
+    return h
+
+
 # --------------------------------------------------------------------------------------
 # helpers
 # --------------------------------------------------------------------------------------
@@ -210,7 +220,7 @@ def voc_layer_shapes(h: dict):
     for i in range(len(h["upsample_rates"])):
         ch = c0 // (2 ** (i + 1))
         for j, k in enumerate(h["resblock_kernel_sizes"]):
-            n_conv = len(h["resblock_dilation_sizes"][j])  # (3 for the shipped ResBlock1 config, 2 for the ResBlock2 goldens)
+            n_conv = 3 if str(h["resblock"]) == "1" else 2  # what the reference constructors build (models.py:17-22,51-54), whatever the list length
             for m in range(n_conv):
                 if str(h["resblock"]) == "1":
                     out.append((f"resblocks.{i * nk + j}.convs1.{m}", "conv", ch, ch, k, 1))

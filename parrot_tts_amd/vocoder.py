@@ -114,10 +114,15 @@ class CodeGenerator(nn.Module):
         self.f0 = get("f0", None)
         self.multispkr = get("multispkr", None)
         # (the reference stores h.f0 and never reads it again: forward() skips the `f0` keyword, models.py:163-164)
-        n_dil = {len(d) for d in self._rb_d}
-        if len(n_dil) != 1 or len(self._rb_d) != len(self._rb_k):
-            raise NotImplementedError("resblock_dilation_sizes must give the same number of dilations per kernel size")
-        self._n_dil = n_dil.pop()
+        # ResBlock1 reads dilation[0], [1], [2] and ResBlock2 dilation[0], [1] -- literally (models.py:17-22,51-54): longer lists
+        # are cut there, shorter ones raise IndexError, so lists of different lengths per kernel size are fine
+        self._n_dil = 3 if self._kind == "1" else 2
+        if len(self._rb_d) < len(self._rb_k):
+            raise IndexError("resblock_dilation_sizes has fewer entries than resblock_kernel_sizes")  # (zip() would silently drop kernels)
+        for d in self._rb_d[:len(self._rb_k)]:
+            if len(d) < self._n_dil:
+                raise IndexError("tuple index out of range")  # what `dilation[%d]` raises in the reference
+        self._rb_d = [d[:self._n_dil] for d in self._rb_d[:len(self._rb_k)]]
         self.num_kernels = len(self._rb_k)
         self.num_upsamples = len(self._rates)
 
@@ -230,6 +235,21 @@ class CodeGenerator(nn.Module):
             f *= u
         return f
 
+    def out_samples(self, units):
+        """Waveform samples of an utterance of ``units`` units (int or integer tensor): the ConvTranspose1d length chain
+        ``(T - 1) u - 2 ((k - u) // 2) + k`` of models.py:80-83 -- ``units * upsample_factor`` for every shipped config, one
+        sample more per stage with odd ``k - u``; 0 for an empty row."""
+        T = units
+        for u, k in zip(self._rates, self._up_k):
+            T = (T - 1) * u - 2 * ((k - u) // 2) + k
+        if isinstance(units, torch.Tensor):
+            return torch.where(units > 0, T, torch.zeros_like(T))
+        return T if units > 0 else 0
+
+    @property
+    def _constant_hop(self) -> bool:
+        return all((k - u) % 2 == 0 for u, k in zip(self._rates, self._up_k))
+
     # ---- forward ------------------------------------------------------------------------------
     def _checked_inputs(self, kwargs, unit_lens):
         """Validate what the C ABI takes as raw device pointers (shared by ``forward`` and the native chunked path): ``code``
@@ -275,14 +295,14 @@ class CodeGenerator(nn.Module):
         if key not in self._ws:
             self._ws = {key: torch.empty(lib.parrot_voc_workspace_bytes(self._handle, B, U), dtype=torch.uint8, device=dev)}
         ws = self._ws[key]
-        wav = torch.empty((B, 1, U * self.upsample_factor), dtype=torch.float32, device=dev)
+        wav = torch.empty((B, 1, self.out_samples(U)), dtype=torch.float32, device=dev)
         stage_ptrs = None
         if stages is not None:  # tests: capture conv_pre / ups_i / mrf_i activations
             names = ["conv_pre"]
             T, bufs = U, []
             bufs.append(torch.empty((B, self._c0, U), dtype=torch.float32, device=dev))
-            for i, u in enumerate(self._rates):
-                T *= u
+            for i, (u, k) in enumerate(zip(self._rates, self._up_k)):
+                T = (T - 1) * u - 2 * ((k - u) // 2) + k
                 ch = self._c0 // (2 ** (i + 1))
                 names += [f"ups{i}", f"mrf{i}"]
                 bufs += [torch.empty((B, ch, T), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -324,6 +344,8 @@ class CodeGenerator(nn.Module):
         code = kwargs["code"]
         if chunk_units <= 0:
             raise ValueError("chunk_units must be positive")
+        if not self._constant_hop:
+            raise NotImplementedError("chunk streaming needs a constant samples-per-unit hop: a stage of this config has odd upsample_kernel_size - upsample_rate")
         halo = self.receptive_units(code.device) if halo_units is None else int(halo_units)
         U, hop = code.shape[1], self.upsample_factor
         for start in range(0, U, chunk_units):
@@ -343,6 +365,8 @@ class CodeGenerator(nn.Module):
         """``forward`` in chunks: same result, bounded activation memory.  Without extra conditioning keywords the chunk loop
         runs inside the library (``parrot_voc_forward_chunked``); otherwise it is assembled from ``stream`` chunks."""
         code = kwargs["code"]
+        if not self._constant_hop:
+            raise NotImplementedError("chunk streaming needs a constant samples-per-unit hop: a stage of this config has odd upsample_kernel_size - upsample_rate")
         if not [k for k in kwargs if k not in ("code", "spkr", "f0")] and self._in_dim == self._emb_dim * (2 if self.multispkr else 1):
             code, spkr, lens32 = self._checked_inputs(kwargs, unit_lens)  # (raw pointers cross the ABI below)
             dev = code.device

@@ -254,6 +254,8 @@ def test_wav_to_int16_matches_numpy_cast():
 def _voc_cfg(name):
     if name.startswith("voc_full"):
         return synth.default_voc_config()
+    if name == "voc_small_corners":  # odd k - u upsampling stages (T u + 1 samples), dilation lists of unequal length
+        return synth.corner_voc_config()
     h = synth.small_voc_config()
     if name == "voc_small_singlespk":
         h["multispkr"] = None
@@ -271,7 +273,7 @@ def _gen(h, sd):
 
 
 VOC_GOLDENS = ["voc_small", "voc_small_singlespk", "voc_small_resblock2", "voc_full_stages", "voc_full_u40", "voc_full_u40_hot",
-               "voc_full_u256"]
+               "voc_full_u256", "voc_small_corners"]
 
 
 def _skip_duplicate_mode(prec, fused):

@@ -114,3 +114,39 @@ def test_pipeline_fails_loudly_by_default_when_the_waveform_leaves_the_fp16_rang
     bad(batch)  # the flag was cleared when it was reported; this forward raises it again ...
     with pytest.raises(FloatingPointError):
         bad.check()  # ... and the explicit check (a sync) covers the last call
+
+
+def test_odd_upsampling_stages_ragged_rows_equal_single_utterance_runs():
+    """stages with odd upsample_kernel_size - upsample_rate yield T u + 1 samples (reference models.py:80-83).  A
+    padded batch with per-row unit counts must give each row the waveform of the reference's B = 1 run of that utterance --
+    `out_samples(n)` real samples per row -- and chunk streaming (no constant hop) must refuse instead of guessing."""
+    h = synth.corner_voc_config()
+    sd = synth.synth_voc_state_dict(h, seed=13, scale=1.0)
+    g = _gen(h, sd)
+    b = synth.synth_voc_batch(4, 23, h, seed=9)
+    lens = [23, 12, 1, 7]
+    wav = g(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV), unit_lens=torch.tensor(lens, device=DEV)).cpu()
+    g.check_inputs()
+    assert wav.shape == (4, 1, g.out_samples(23)) and g.out_samples(23) == ((23 * 4 + 1) * 2) * 2 + 1
+    for r, n in enumerate(lens):
+        with torch.no_grad():
+            ref = O.code_generator_forward(sd, h, b["code"][r:r + 1, :n], b["spkr"][r:r + 1])
+        assert ref.shape[-1] == g.out_samples(n)
+        assert float((wav[r:r + 1, :, : ref.shape[-1]] - ref).abs().max()) <= 5e-5, (r, n)
+    with pytest.raises(NotImplementedError):
+        g.forward_chunked(chunk_units=8, code=b["code"].to(DEV), spkr=b["spkr"].to(DEV))
+
+
+def test_duration_predictor_kernel_other_than_3_is_refused_like_the_reference(tmp_path):
+    """The reference raises RuntimeError in DurationPredictor.forward for kernel_size != 3 (padding=1 is hard-coded,
+    duration.py:34,45-46): the HIP handle refuses the config with a RuntimeError as well."""
+    cfg = synth.small_tte_config()
+    cfg["path"]["root_path"] = str(tmp_path)
+    cfg["duration_predictor"]["kernel_size"] = 5
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({"a": 0}, f)
+    m = Parrot(cfg, 20, 0)
+    m.load_state_dict(synth.synth_tte_state_dict(cfg, 20, 1, seed=2))
+    batch = {k: v.to(DEV) for k, v in synth.synth_tte_batch(2, 9, 20, 1, seed=1, ragged=True).items()}
+    with pytest.raises(RuntimeError):
+        m.eval().to(DEV).infer(batch)

@@ -210,3 +210,44 @@ def test_profile_kernel_names_fold_to_bench_rows():
     for raw, want in cases.items():
         assert mod.norm(raw) == want
         assert want in bench.tile_names("f16x3")
+
+
+def test_resblock_dilation_lists_follow_the_reference_constructors():
+    """ResBlock1 reads dilation[0..2], ResBlock2 dilation[0..1] -- literally (reference utils/vocoder/models.py:17-22,51-54):
+    longer lists are cut, shorter ones raise IndexError, lists of different lengths per kernel size are accepted."""
+    import pytest
+    from parrot_tts_amd import synth
+    from parrot_tts_amd.vocoder import AttrDict, CodeGenerator
+    h = synth.corner_voc_config()
+    g = CodeGenerator(AttrDict(h))
+    keys = set(g.state_dict())
+    assert set(synth.synth_voc_state_dict(h, seed=1)) == keys
+    assert "resblocks.1.convs1.2.weight_v" in keys and "resblocks.1.convs1.3.weight_v" not in keys
+    h["resblock_dilation_sizes"] = [[1, 3], [1, 3, 5], [1, 3, 5]]
+    with pytest.raises(IndexError):
+        CodeGenerator(AttrDict(h))
+    h["resblock"] = "2"
+    g2 = CodeGenerator(AttrDict(h))
+    assert "resblocks.2.convs.1.bias" in g2.state_dict() and "resblocks.2.convs.2.bias" not in g2.state_dict()
+    # out_samples: the ConvTranspose1d length chain (T u + 1 per odd stage), 0 for an empty row
+    g3 = CodeGenerator(AttrDict(synth.corner_voc_config()))
+    assert g3.out_samples(11) == ((11 * 4 + 1) * 2) * 2 + 1 and g3.out_samples(0) == 0 and g3.upsample_factor == 16
+    import torch
+    assert g3.out_samples(torch.tensor([0, 1, 11])).tolist() == [0, ((1 * 4 + 1) * 2) * 2 + 1, 181]
+    assert CodeGenerator(AttrDict(synth.small_voc_config())).out_samples(7) == 7 * 320
+
+
+def test_duration_predictor_kernel_other_than_3_fails_like_the_reference():
+    """duration.py:30-34 hard-codes padding=1 for the second conv: with kernel_size != 3 its output has S - k + 3 frames and the
+    reference's own `masked_fill(mask)` (duration.py:45-46, always reached from Parrot.forward) raises RuntimeError.  The oracle
+    restates that; the HIP handle refuses such a config at create (a RuntimeError subclass) instead of inventing a result."""
+    import pytest
+    import torch
+    from oracle import parrot_oracle as O
+    from parrot_tts_amd import synth
+    cfg = synth.small_tte_config()
+    cfg["duration_predictor"]["kernel_size"] = 5
+    sd = synth.synth_tte_state_dict(cfg, 20, 1, seed=2)
+    batch = synth.synth_tte_batch(2, 9, 20, 1, seed=1, ragged=True)
+    with pytest.raises(RuntimeError), torch.no_grad():
+        O.tte_forward(sd, cfg, batch)

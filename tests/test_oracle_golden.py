@@ -76,6 +76,8 @@ def test_tte_blocks(golden_dir):
 def _voc_cfg(name):
     if name.startswith("voc_full"):
         return synth.default_voc_config()
+    if name == "voc_small_corners":  # odd k - u upsampling stages (T u + 1 samples), dilation lists of unequal length
+        return synth.corner_voc_config()
     h = synth.small_voc_config()
     if name == "voc_small_singlespk":
         h["multispkr"] = None
@@ -87,7 +89,7 @@ def _voc_cfg(name):
 
 
 VOC_CASES = ["voc_full_stages", "voc_full_u40", "voc_full_u40_hot", "voc_small", "voc_small_singlespk",
-             "voc_small_resblock2", "voc_full_u256"]
+             "voc_small_resblock2", "voc_full_u256", "voc_small_corners"]
 
 
 @pytest.mark.parametrize("name", VOC_CASES)
@@ -101,7 +103,10 @@ def test_vocoder_oracle_matches_reference(golden_dir, name):
     with torch.no_grad():
         y = O.code_generator_forward(sd, h, code, spkr, stages=st)
         y_folded = O.code_generator_forward(O.fold_weight_norm(sd), h, code, spkr)
-    assert y.shape == (m["B"], 1, m["U"] * int(np.prod(h["upsample_rates"])))
+    n_out = m["U"]
+    for u, k in zip(h["upsample_rates"], h["upsample_kernel_sizes"]):
+        n_out = (n_out - 1) * u - 2 * ((k - u) // 2) + k  # ConvTranspose1d (models.py:80-83): T u, + 1 for odd k - u
+    assert y.shape == (m["B"], 1, n_out)
     assert np.array_equal(y.numpy(), z["wav"])
     assert np.array_equal(y_folded.numpy(), z["wav"]), "weight_g/weight_v and folded checkpoints must agree"
     assert np.array_equal(O.to_int16(y.squeeze(1)), z["wav_int16"])

@@ -222,6 +222,8 @@ def voc_feats_case(name="voc_small_feats"):
 def main():
     if "--only-feats" in sys.argv:  # added later: leaves the other (bit-pinned) goldens untouched
         return voc_feats_case()
+    if "--only-corners" in sys.argv:  # round 3
+        return voc_case("voc_small_corners", synth.corner_voc_config(), B=3, U=11, seed_w=13, seed_in=8, scale=1.0, with_stages=True)
     full_t, small_t = synth.default_tte_config(), synth.small_tte_config()
     # 1. TTE-small: ragged pads, 2 speakers (full-size model)
     tte_case("tte_full_ragged", full_t, vocab=60, n_spk=2, B=3, S=23, seed_w=0, seed_in=1, ragged=True)
