@@ -91,6 +91,7 @@ struct ConvParams {
     int fold_res;            // 1: the residual tile initialises the accumulator (prologue latency hiding); 0: added once in the
                              // epilogue -- what the reference computes (conv, THEN + res): when |res| >> |conv sum| (the TTE's residual
                              // stream) folding makes every accumulation step round at ulp(|res|) instead of ulp(|sum|)
+    int lean;                // conv_split_kernel: buffer-addressed prologue / epilogue for plain convs (conv_acc_init_lean)
     float acc_scale;         // split schemes with pre-scaled operands (conv_split.h): the accumulator holds acc_scale * sum
     float out_scale;         // = 1 / acc_scale (both exact powers of two; 1 for every other kernel)
 };
@@ -284,6 +285,126 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 for (int q = 0; q < 8; ++q)
                     if (off[q] >= 0) yb[off[q]] = v[q];
             }
+        }
+    }
+}
+
+// ---- lean accumulator init / epilogue for PLAIN convs (u == 1) -----------------------------------------------------------
+// The generic versions above address every element with 64-bit pointer arithmetic and per-element bounds selects: ~25 VALU
+// instructions per accumulator register in the prologue and the epilogue together -- more VALU time than the main loop's MFMAs
+// on the short-K layers (128 channels: 4 chunks), and VALU beside another wave's MFMAs costs 2-3x its stand-alone rate
+// (tools/probes/valu_rates.hip).  Here a row-major (M, Tout) fp32 tile is accessed through buffer instructions: the
+// lane-dependent part of an element's byte offset is ONE VGPR per column tile (0x80000000 when the column is out of range:
+// loads return 0, stores are dropped), the row part is a scalar offset, rows >= M fall beyond num_records = M * Tout * 4.
+// Same arithmetic in the same order as the generic code (results equal; an exact zero may come out as +0 instead of -0).
+struct RowTile {
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ RowTile row_tile(const float* base, int rows, int row_elems) {
+    const size_t a = reinterpret_cast<size_t>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    RowTile t;
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)hi << 32) | lo), 0,
+                                               __builtin_amdgcn_readfirstlane(rows * row_elems * 4), 0x00020000);
+    return t;
+}
+__device__ __forceinline__ float row_tile_load(const RowTile& t, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rsrc, voff, soff, 0));
+}
+__device__ __forceinline__ void row_tile_store(const RowTile& t, float v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), t.rsrc, voff, soff, 0);
+}
+// plain convs whose (M, Tout) tile of one batch row fits 31-bit byte offsets (every layer of the path) take the lean code
+__host__ __device__ __forceinline__ bool conv_lean_ok(const ConvParams& p) { return p.lean != 0 && p.u == 1 && (long)p.M * p.Tout * 4 < 0x7fffffffL; }
+
+// 32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+template <int WM, int WN>
+__device__ __forceinline__ void conv_acc_init_lean(const ConvParams& p, f32x16 (&acc)[WM][WN], int b, int m_wave, int n_wave, int half, int l31) {
+    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    const bool fold_res = rb != nullptr && p.act == ACT_NONE && p.fold_res != 0;
+    const int row_bytes = p.Tout * 4;
+    int vo[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        const int n = n_wave + nt * 32 + l31;
+        vo[nt] = (n < p.Ncols) ? (4 * half * p.Tout + n) * 4 : (int)0x80000000;
+    }
+    const RowTile rt = row_tile(fold_res ? rb : p.x, p.M, p.Tout);  // (p.x: never read when !fold_res)
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int m0 = m_wave + mt * 32;  // wave-uniform
+        if (fold_res) {  // (the residual loads go out first: the longest latency of the prologue)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = row_tile_load(rt, vo[nt], (m0 + (r & 3) + 8 * (r >> 2)) * row_bytes);
+        }
+        float bs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bs[r] = p.bias ? p.bias[min(m0 + 4 * half + (r & 3) + 8 * (r >> 2), p.M - 1)] * p.acc_scale : 0.f;
+        if (fold_res) {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], p.acc_scale, bs[r]);  // = (res + bias) * scale, one rounding
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bs[r];
+        }
+    }
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (&acc)[WM][WN], int b, int m_wave, int n_wave, int half, int l31) {
+    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
+    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    const bool fold_res = rb != nullptr && p.act == ACT_NONE && p.fold_res != 0;
+    const bool late_res = rb != nullptr && !fold_res;
+    const bool has_acc = p.epi != EPI_STORE;
+    const bool do_div = p.epi == EPI_ADD_DIV;
+    const bool relu = p.act == ACT_RELU;
+    const int row_bytes = p.Tout * 4;
+    int vo[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        const int n = n_wave + nt * 32 + l31;
+        vo[nt] = (n < p.Ncols) ? (4 * half * p.Tout + n) * 4 : (int)0x80000000;
+    }
+    const RowTile yt = row_tile(yb, p.M, p.Tout), rt = row_tile(late_res ? rb : yb, p.M, p.Tout);
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int m0 = m_wave + mt * 32;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[mt][nt][r] * p.out_scale;
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (late_res) {
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = row_tile_load(rt, vo[nt], (m0 + (r & 3) + 8 * (r >> 2)) * row_bytes);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] + rv[r];
+            }
+            if (has_acc) {
+                float yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = row_tile_load(yt, vo[nt], (m0 + (r & 3) + 8 * (r >> 2)) * row_bytes);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = yv[r] + v[r];
+                if (do_div) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] / p.div;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) row_tile_store(yt, v[r], vo[nt], (m0 + (r & 3) + 8 * (r >> 2)) * row_bytes);
         }
     }
 }

@@ -143,7 +143,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // K == 0: any tap count, flat two-step walk with uniform branches at the chunk boundaries.
 // SUBS > 1 (1x1 convs only): SUBS 16-channel sub-slabs are staged per barrier and no halo columns at all -- a 1x1 conv
 // otherwise pays one barrier, one conversion pass over tile + 64 halo columns and one pipeline bubble per MFMA step.
-template <class SCH, int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1>
+// LEAN: plain convs only (u == 1): the buffer-addressed prologue / epilogue of conv_mfma.h (a separate instantiation: carrying
+// both code paths in one kernel costs registers -- spills on the 2x2 wave tile).
+template <class SCH, int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1, bool LEAN = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel(const ConvParams p) {
     static_assert(SUBS == 1 || K == 1 || K == 3, "sub-slab staging: 1x1 convs (no halo) and k = 3 (two 16-channel slabs per barrier)");
     constexpr int NPC = SCH::NP, NTERM = SCH::NT;
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
     f32x16 acc[WM][WN];
     const int m_wave = mblock * BM + wm * WM * 32;
     const int n_wave = t0 + wn * WN * 32;
-    conv_acc_init<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
+    if constexpr (LEAN) conv_acc_init_lean<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
+    else conv_acc_init<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 
     // A stream: n_it = nchunks * k steps per m-tile, STEP_BYTES per step ([piece][lane][8 x 16 bit]).
     // Weight stream addressing: one buffer descriptor (SGPR quad) for the whole packed stream, a constant per-lane byte
@@ -451,14 +454,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
             if (st + 1 < total) step(a1, b1, a0, b0);
         }
     }
-    conv_epilogue<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
+    if constexpr (LEAN) conv_epilogue_lean<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
+    else conv_epilogue<WM, WN>(p, acc, b, m_wave, n_wave, half, l31);
 }
 
-template <class SCH, int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1>
+template <class SCH, int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1, bool LEAN = false>
 inline hipError_t launch_conv_split_t(const ConvParams& p, dim3 grid, hipStream_t s) {
     constexpr int BN = WAVES_N * WN * 32;
     const size_t lds = (size_t)2 * SUBS * SCH::NP * (BN + ((SUBS > 1 && K == 1) ? 0 : CONV_HALO)) * 32;
-    auto kern = conv_split_kernel<SCH, WAVES_M, WAVES_N, WM, WN, MINW, K, SUBS>;
+    auto kern = conv_split_kernel<SCH, WAVES_M, WAVES_N, WM, WN, MINW, K, SUBS, LEAN>;
     static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
     {
         hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), (size_t)lds);
@@ -494,8 +498,10 @@ inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStrea
     split_tile(variant, bm, bn);
     dim3 grid(split_grid(p, bm));
     if (variant == 3) return p.k == 3 ? launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 3>(p, grid, s) : launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 0>(p, grid, s);
+    const bool lean = conv_lean_ok(p);  // plain conv: the instantiation with the buffer-addressed prologue / epilogue
     if (variant == 2) {
-        if (p.k == 1 && p.nchunks % 4 == 0) return launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4>(p, grid, s);  // 64 channels per barrier
+        if (p.k == 1 && p.nchunks % 4 == 0)  // 64 channels per barrier
+            return lean ? launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4, true>(p, grid, s) : launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4>(p, grid, s);
         switch (p.k) {  // (k > 1: sequences of <= 64 steps, i.e. the TTE encoder side)
             case 1: return launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1>(p, grid, s);
             case 3: return launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 3>(p, grid, s);
@@ -513,7 +519,7 @@ inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStrea
     switch (p.k) {
         case 3:
             if (split_k3_subs2() && p.nchunks % 2 == 0 && SCH::NP <= 2) return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3, 2>(p, grid, s);  // 32 channels per barrier
-            return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3>(p, grid, s);
+            return lean ? launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3, 1, true>(p, grid, s) : launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3>(p, grid, s);
         case 7: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 7>(p, grid, s);
         case 9: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 9>(p, grid, s);
         case 11: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 11>(p, grid, s);

@@ -98,27 +98,46 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void conv_split16_kernel(
     };
 
     // ---- accumulators: C/D layout of 16x16 MFMA: column l & 15, rows 4 (l >> 4) + r --------------------------------
+    // Prologue and epilogue address the (M, Tout) output / residual tile through buffer instructions (conv_mfma.h, RowTile): one
+    // VGPR of lane-dependent offset per column tile, scalar row offsets, out-of-range columns / rows dropped by the hardware --
+    // a few VALU instructions per accumulator register instead of ~25 (pointer arithmetic + bounds selects per element).
     f32x4 acc[TM][TN];
     const int m_wave = mblock * BM + wm * TM * 16;
     const int n_wave = t0 + wn * TN * 16;
     float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
     const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
     const bool fold_res = rb != nullptr && p.act == ACT_NONE && p.fold_res != 0;
+    const int out_row_bytes = p.Tout * 4;
+    int vo[TN];  // byte offset of this lane's (row 4 g4, column) inside the tile rows; 0x80000000: column out of range
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n_wave + tn * 16 + l15;
+        vo[tn] = (n < p.Ncols) ? (4 * g4 * p.Tout + n) * 4 : (int)0x80000000;
+    }
     {
+        const RowTile rt = row_tile(fold_res ? rb : p.x, p.M, p.Tout);  // (never read when !fold_res)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
+            const int m0 = m_wave + tm * 16;  // wave-uniform
+            if (fold_res) {  // (the residual loads go out first: the longest latency of the prologue)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tm][tn][r] = row_tile_load(rt, vo[tn], (m0 + r) * out_row_bytes);
+            }
             float bs[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bs[r] = p.bias ? p.bias[min(m_wave + tm * 16 + 4 * g4 + r, p.M - 1)] : 0.f;
+            for (int r = 0; r < 4; ++r) bs[r] = p.bias ? p.bias[min(m0 + 4 * g4 + r, p.M - 1)] * p.acc_scale : 0.f;
+            if (fold_res) {
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int n = n_wave + tn * 16 + l15;
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m_wave + tm * 16 + 4 * g4 + r;
-                    const float rv = fold_res ? rb[(n < p.Ncols && m < p.M) ? m * p.Tout + n : 0] : 0.f;
-                    acc[tm][tn][r] = (rv + bs[r]) * p.acc_scale;
-                }
+                    for (int r = 0; r < 4; ++r) acc[tm][tn][r] = fmaf(acc[tm][tn][r], p.acc_scale, bs[r]);  // = (res + bias) * scale
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tm][tn][r] = bs[r];
             }
         }
     }
@@ -208,39 +227,59 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void conv_split16_kernel(
     }
 
     // ---- epilogue (plain convs only): scale back, late residual / activation / MRF accumulation modes ------------------
+    // v = y_old + (max(acc * out_scale, relu ? 0 : -inf) + res): the same operations in the same order as conv_epilogue
     const bool late_res = rb != nullptr && !fold_res;
     const bool has_acc = p.epi != EPI_STORE;
     const bool do_div = p.epi == EPI_ADD_DIV;
-    const float act_lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    const bool relu = p.act == ACT_RELU;
+    const RowTile yt = row_tile(yb, p.M, p.Tout), rt = row_tile(late_res ? rb : yb, p.M, p.Tout);
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m0 = m_wave + tm * 16;
+        float v[TN][4];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n_wave + tn * 16 + l15;
-            int off[4];
-            float rv[4], yv[4];
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_wave + tm * 16 + 4 * g4 + r;
-                off[r] = (n < p.Ncols && m < p.M) ? m * p.Tout + n : -1;
-                rv[r] = 0.f;
-                yv[r] = 0.f;
-            }
-            if (late_res) {
+            for (int r = 0; r < 4; ++r) v[tn][r] = acc[tm][tn][r] * p.out_scale;
+        if (relu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rv[r] = rb[off[r] < 0 ? 0 : off[r]];
-            }
-            if (has_acc) {
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yv[r] = yb[off[r] < 0 ? 0 : off[r]];
-            }
+                for (int r = 0; r < 4; ++r) v[tn][r] = fmaxf(v[tn][r], 0.f);
+        }
+        if (late_res) {
+            float rv[TN][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = yv[r] + (fmaxf(acc[tm][tn][r] * p.out_scale, act_lo) + rv[r]);
-                if (do_div) v = v / p.div;
-                if (off[r] >= 0) yb[off[r]] = v;
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rv[tn][r] = row_tile_load(rt, vo[tn], (m0 + r) * out_row_bytes);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[tn][r] = v[tn][r] + rv[tn][r];
+        }
+        if (has_acc) {
+            float yv[TN][4];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[tn][r] = row_tile_load(yt, vo[tn], (m0 + r) * out_row_bytes);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[tn][r] = yv[tn][r] + v[tn][r];
+            if (do_div) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[tn][r] = v[tn][r] / p.div;
             }
         }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) row_tile_store(yt, v[tn][r], vo[tn], (m0 + r) * out_row_bytes);
+    }
 }
 
 template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K>

@@ -512,6 +512,10 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.groups = c->groups; p.Mg = c->Mg;
     p.row_len = row_len; p.row_len_mul = row_len_mul; p.row_len_add = row_len_add;
     p.acc_scale = p.out_scale = 1.f;
+    {   // PARROT_LEAN_EPI (conv_split_kernel): 1 buffer-addressed prologue / epilogue for plain convs, 0 the generic one
+        static const int lean = [] { const char* e = getenv("PARROT_LEAN_EPI"); return e ? atoi(e) : 1; }();
+        p.lean = lean;
+    }
     p.fold_res = c->late_res ? 0 : 1;
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;

@@ -184,7 +184,7 @@ def test_resblock2_at_full_width(prec):
 NON_DEFAULT_VOC = [
     dict(upsample_rates=[8, 5, 2, 2], upsample_kernel_sizes=[16, 11, 4, 4], upsample_initial_channel=128),
     dict(upsample_rates=[4, 4], upsample_kernel_sizes=[8, 8], upsample_initial_channel=64, resblock_kernel_sizes=[3, 5],
-         resblock_dilation_sizes=[[1, 2], [2, 6]]),
+         resblock_dilation_sizes=[[1, 2, 3], [2, 6, 1, 9]]),  # (ResBlock1 reads three entries per list: models.py:17-22)
     dict(upsample_rates=[5, 4, 4, 2, 2], upsample_kernel_sizes=[11, 8, 8, 4, 4], upsample_initial_channel=256,
          resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], multispkr=None, model_in_dim=16),
 ]
