@@ -246,6 +246,14 @@ int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L,
  * reference's Embedding IndexError) or PARROT_E_NONFINITE (NaN / inf logits at some position of the last decode: an
  * activation beyond the fp16 split scheme's range -- the ids of that call are not to be trusted). */
 int parrot_tte_check(parrot_tte_t*, void* stream);
+/* Tie guard of the unit-id argmax (reference modules/parrot.py:115: torch.argmax over 1000 fp32 logits).  parrot_tte_decode
+ * measures every position's top-2 margin; where it is below PARROT_TIE_GUARD (default 1e-4; 0 = off) the head is re-evaluated
+ * for that position in fp64 (exact products of the fp32 weights and activations, no accumulation-order dependence) and the
+ * argmax taken again.  dst_dev[0..2] <- {guarded positions of the last decode, ids the re-evaluation changed, its smallest
+ * margin (float bits)}; no synchronisation.  What no implementation can do is follow the reference below ITS OWN noise: its
+ * fp32 logits move by ~1.2e-5 with the CPU thread count (tests/test_oracle_golden.py), so an id with a smaller margin is not
+ * determined by the reference itself. */
+int parrot_tte_guard_stats_async(parrot_tte_t*, int32_t* dst_dev, void* stream);
 /* The same flag without a synchronisation (3 / 4 bad phone / speaker id, 5 non-finite logits): see parrot_voc_status_async. */
 int parrot_tte_status_async(parrot_tte_t*, int32_t* dst_dev, void* stream);
 /* Tests / error localisation: while set, the next encode / decode calls copy the channel-first (B, D, T) activation

@@ -98,6 +98,7 @@ SIGNATURES = {
     "parrot_tte_decode": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_check": (C.c_int, [vp, vp]),
     "parrot_tte_status_async": (C.c_int, [vp, vp, vp]),
+    "parrot_tte_guard_stats_async": (C.c_int, [vp, vp, vp]),
     "parrot_tte_debug_stages": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "parrot_length_regulator_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "parrot_length_regulator": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),

@@ -290,10 +290,13 @@ static __global__ __launch_bounds__(256) void dur_prefix_kernel(const int64_t* _
 // ---------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ enc, const int32_t* __restrict__ cum,
                                                               const int32_t* __restrict__ out_len, const float* __restrict__ pe_row,
-                                                              float* __restrict__ y, uint8_t* __restrict__ tgt_mask, int S, int L, int D) {
+                                                              float* __restrict__ y, uint8_t* __restrict__ tgt_mask, int S, int L, int D,
+                                                              int* __restrict__ gstat = nullptr) {
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6;  // lane = frame, the four waves split the channels
     const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    // (first kernel of a decode: restart the tie-guard statistics {count, ids changed, min margin bits = +inf} of argmax_cf_kernel)
+    if (gstat && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) gstat[threadIdx.x] = threadIdx.x == 2 ? 0x7f800000 : 0;
     if (t >= L) return;
     const int len = out_len[b];
     if (wave == 0) tgt_mask[(size_t)b * L + t] = (t <= len) ? 1 : 0;
@@ -316,45 +319,104 @@ static __global__ __launch_bounds__(256) void length_regulate_kernel(const float
 }
 
 // argmax over channels of (B, V, L) logits -> ids (B, L); first maximal index wins (torch.argmax).
-// Optionally also writes logits transposed to the reference's (B, L, V) layout for tests.
+// Tie guard (reference modules/parrot.py:115 takes the argmax of 1000 fp32 logits): every position also yields its top-2
+// margin; positions whose margin is below `guard` are appended to `glist` ((b, t) pairs, at most TIE_GUARD_MAX) and counted in
+// gstat[0], the smallest margin of the call lands in gstat[2] (float bits; positive floats order like ints) --
+// tie_guard_refine_kernel then re-evaluates the head for exactly those positions in fp64.
+constexpr int TIE_GUARD_MAX = 256;
 static __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L,
-                                                               int* __restrict__ err) {
+                                                               int* __restrict__ err, float guard, int* __restrict__ glist,
+                                                               int* __restrict__ gstat) {
     // lane = time step; the four waves scan a quarter of the vocabulary each, then the first maximum wins
     // (strict > inside a range, lower range first on ties: torch.argmax's first-occurrence rule)
-    __shared__ float bv[4][64];
-    __shared__ int bix[4][64];
+    __shared__ float bv[4][64], sv[4][64];
+    __shared__ int bix[4][64], bad[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int t = blockIdx.x * 64 + lane;
     const bool ok = t < L;
     const int per = (V + 3) / 4, v0 = wave * per, v1 = min(V, v0 + per);
     const float* lb = logits + (size_t)b * V * L + (ok ? t : 0);
-    float best = -INFINITY;
-    int bi = v0 < V ? v0 : 0;
-    if (v0 < V) best = lb[(size_t)v0 * L];
+    float best = -INFINITY, second = -INFINITY;  // second: the largest value of the range that is not `best`'s element
+    int bi = v0 < V ? v0 : 0, nonfinite = 0;
+    auto take = [&](float x, int v) {
+        nonfinite |= !(fabsf(x) < INFINITY);  // NaN / inf anywhere in the column (a NaN never wins a `>` comparison)
+        if (x > best) { second = best; best = x; bi = v; }
+        else if (x > second) second = x;
+    };
+    if (v0 < V) {
+        best = lb[(size_t)v0 * L];
+        nonfinite |= !(fabsf(best) < INFINITY);
+    }
     int v = v0 + 1;
     for (; v + 3 < v1; v += 4) {
         const float x0 = lb[(size_t)v * L], x1 = lb[(size_t)(v + 1) * L], x2 = lb[(size_t)(v + 2) * L], x3 = lb[(size_t)(v + 3) * L];
-        if (x0 > best) { best = x0; bi = v; }
-        if (x1 > best) { best = x1; bi = v + 1; }
-        if (x2 > best) { best = x2; bi = v + 2; }
-        if (x3 > best) { best = x3; bi = v + 3; }
+        take(x0, v); take(x1, v + 1); take(x2, v + 2); take(x3, v + 3);
     }
-    for (; v < v1; ++v) {
-        const float x = lb[(size_t)v * L];
-        if (x > best) { best = x; bi = v; }
-    }
+    for (; v < v1; ++v) take(lb[(size_t)v * L], v);
     bv[wave][lane] = best;
+    sv[wave][lane] = second;
     bix[wave][lane] = bi;
+    bad[wave][lane] = nonfinite;
     __syncthreads();
     if (wave == 0 && ok) {
-        float m = bv[0][lane];
-        int mi = bix[0][lane];
+        float m = bv[0][lane], s2 = sv[0][lane];
+        int mi = bix[0][lane], nf = bad[0][lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (bv[w][lane] > m) { m = bv[w][lane]; mi = bix[w][lane]; }
+        for (int w = 1; w < 4; ++w) {
+            const float bw = bv[w][lane];
+            nf |= bad[w][lane];
+            if (bw > m) { s2 = fmaxf(fmaxf(s2, m), sv[w][lane]); m = bw; mi = bix[w][lane]; }
+            else s2 = fmaxf(s2, fmaxf(bw, sv[w][lane]));
+        }
         ids[(size_t)b * L + t] = mi;
-        if (err && !(fabsf(m) < INFINITY)) atomicExch(err, 5);  // NaN / inf logits (an activation left the fp16 split range)
+        if (err && nf) atomicExch(err, 5);  // NaN / inf logits (an activation left the fp16 split range)
+        if (gstat) {
+            const float margin = m - s2;  // >= 0 (NaN when non-finite: flagged above, fails the comparisons below)
+            if (margin >= 0.f) atomicMin(gstat + 2, __float_as_int(margin));
+            if (margin < guard) {
+                const int slot = atomicAdd(gstat, 1);
+                if (slot < TIE_GUARD_MAX) { glist[2 * slot] = b; glist[2 * slot + 1] = t; }
+            }
+        }
+    }
+}
+
+// One workgroup per guarded position: logits[v] = head_b[v] + sum_c head_w[v][c] * x[b][c][t] in fp64 (exact products, one
+// rounding-free sum: the argmax no longer depends on the accumulation order of the head), first maximum wins.
+static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const float* __restrict__ x, const float* __restrict__ hw,
+                                                                      const float* __restrict__ hb, int64_t* __restrict__ ids, int D, int V,
+                                                                      int L, const int* __restrict__ glist, int* __restrict__ gstat) {
+    const int n = min(gstat[0], TIE_GUARD_MAX);
+    if ((int)blockIdx.x >= n) return;
+    extern __shared__ double xs[];  // D activations of the position + the reduction scratch
+    __shared__ double rv[256];
+    __shared__ int ri[256];
+    const int b = glist[2 * blockIdx.x], t = glist[2 * blockIdx.x + 1];
+    for (int c = threadIdx.x; c < D; c += 256) xs[c] = (double)x[((size_t)b * D + c) * L + t];
+    __syncthreads();
+    double best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float* w = hw + (size_t)v * D;
+        double acc = hb ? (double)hb[v] : 0.0;
+        for (int c = 0; c < D; ++c) acc = fma((double)w[c], xs[c], acc);
+        if (acc > best) { best = acc; bi = v; }  // (v ascending per thread: the first maximum is kept)
+    }
+    rv[threadIdx.x] = best;
+    ri[threadIdx.x] = bi;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) {
+            const double o = rv[threadIdx.x + sft];
+            const int oi = ri[threadIdx.x + sft];
+            if (o > rv[threadIdx.x] || (o == rv[threadIdx.x] && oi < ri[threadIdx.x])) { rv[threadIdx.x] = o; ri[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (ids[(size_t)b * L + t] != ri[0]) atomicAdd(gstat + 1, 1);  // positions whose id the refinement changed
+        ids[(size_t)b * L + t] = ri[0];
     }
 }
 

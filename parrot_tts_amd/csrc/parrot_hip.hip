@@ -24,6 +24,7 @@
 #include "resblock_split.h"
 #include "resblock_split16.h"
 #include "resblock_dual.h"
+#include "resblock_pdual.h"
 #include "resblock_fused.h"
 
 using namespace parrot;
@@ -972,8 +973,10 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         // PARROT_RB_DUAL (experiments, resblock_dual.h; measured slower): 0 (default) the kernels of
         // resblock_split.h, 1 the lean-VALU variant with one window per workgroup, 2 dual-window anti-phase workgroups
         static const int dual_mode = [] { const char* e = getenv("PARROT_RB_DUAL"); return e ? atoi(e) : 0; }();
+        // 3: the persistent dual-window kernel (resblock_pdual.h; 32 / 64 channels)
         HIP_TRY(k16 ? launch_resblock_split16(v->scheme, C, p, s)
-                    : (dual_mode > 0 && resblock_dual_has(v->scheme, C)) ? launch_resblock_dual_f16x3(C, dual_mode == 2 ? 2 : 1, p, s)
+                    : (dual_mode == 3 && resblock_pdual_has(v->scheme, C)) ? launch_resblock_pdual_f16x3(C, p, g_num_cus, s)
+                    : (dual_mode > 0 && dual_mode < 3 && resblock_dual_has(v->scheme, C)) ? launch_resblock_dual_f16x3(C, dual_mode == 2 ? 2 : 1, p, s)
                                                                           : launch_resblock_split(v->scheme, C, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
         src = p.y;
@@ -1228,10 +1231,17 @@ struct parrot_tte {
     std::vector<float*> dbg_enc, dbg_dec;  // parrot_tte_debug_stages (tests only)
     int scheme = 0;                        // PARROT_PREC_* captured at create
     bool flash = false;                    // attention core on attn_flash_kernel (any T, no score tensor)
+    // tie guard (argmax_cf_kernel / tie_guard_refine_kernel): fp32 head weights for the fp64 re-evaluation, the (b, t) list of
+    // the last decode's low-margin positions and its statistics {count, min margin bits, ids changed}
+    float *head_w = nullptr, *head_b = nullptr;
+    int *glist = nullptr, *gstat = nullptr;
+    float guard = 1e-4f;
     ~parrot_tte() {
-        for (float* p : {pe, tok, spk, ln0_w, ln0_b, ln1_w, ln1_b})
+        for (float* p : {pe, tok, spk, ln0_w, ln0_b, ln1_w, ln1_b, head_w, head_b})
             if (p) (void)hipFree(p);
         if (err) (void)hipFree(err);
+        if (glist) (void)hipFree(glist);
+        if (gstat) (void)hipFree(gstat);
     }
 };
 
@@ -1333,6 +1343,15 @@ extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, 
     for (int i = 0; i < c.enc_layers; ++i) TRY(build_fft(t->enc[i], c, c.enc_heads, w->enc[i]));
     for (int i = 0; i < c.dec_layers; ++i) TRY(build_fft(t->dec[i], c, c.dec_heads, w->dec[i]));
     TRY(make_conv(t->head, D, c.n_codes, 1, 1, 0, 0, 1, PRE_NONE, 0.f, ACT_NONE, w->head_w, w->head_b));
+    {   // tie guard: PARROT_TIE_GUARD = margin below which a position's head is re-evaluated in fp64 (0 switches it off)
+        const char* e = getenv("PARROT_TIE_GUARD");
+        t->guard = e ? (float)atof(e) : 1e-4f;
+        TRY(upload(&t->head_w, w->head_w, (size_t)c.n_codes * D));
+        if (w->head_b) TRY(upload(&t->head_b, w->head_b, (size_t)c.n_codes));
+        HIP_TRY(hipMalloc((void**)&t->glist, 2 * TIE_GUARD_MAX * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&t->gstat, 4 * sizeof(int)));
+        HIP_TRY(hipMemset(t->gstat, 0, 4 * sizeof(int)));
+    }
     *out = t.release();
     return PARROT_OK;
 }
@@ -1522,7 +1541,7 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
     if (!sa.ok || !a.ok) return fail(PARROT_E_NOMEM, "tte_decode: state/workspace too small");
     const int D = c.d_model, V = c.n_codes;
     hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, st.enc_out, st.cum, st.out_len,
-                       t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D);
+                       t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D, t->guard > 0.f ? t->gstat : nullptr);
     HIP_TRY(hipGetLastError());
     auto dbg = [&](size_t idx, const float* src, size_t n) -> int {
         if (idx < t->dbg_dec.size() && t->dbg_dec[idx]) HIP_TRY(hipMemcpyAsync(t->dbg_dec[idx], src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1534,8 +1553,17 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
         TRY(dbg(1 + n, w.x, (size_t)B * D * L));
     }
     TRY(conv_launch(t->head.get(), w.x, nullptr, w.logits, B, L, EPI_STORE, 1.f, 0, 0, 0, s));
-    hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, w.logits, ids, V, L, t->err);
-    HIP_TRY(hipGetLastError());
+    {   // argmax + tie guard: gstat = {count, ids changed, min margin (float bits)} of this decode
+        const bool on = t->guard > 0.f;  // (length_regulate_kernel, the first kernel of this decode, has reset gstat)
+        hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, w.logits, ids, V, L, t->err, t->guard,
+                           on ? t->glist : nullptr, on ? t->gstat : nullptr);
+        HIP_TRY(hipGetLastError());
+        if (on) {  // re-evaluate the head of the low-margin positions in fp64 (workgroups beyond the count exit at once)
+            hipLaunchKernelGGL(tie_guard_refine_kernel, dim3(TIE_GUARD_MAX), dim3(256), (size_t)D * sizeof(double), s, w.x, t->head_w, t->head_b,
+                               ids, D, V, L, t->glist, t->gstat);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     if (logits) {
         hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((L + 63) / 64, (V + 63) / 64, B), dim3(256), 0, s, w.logits, logits, V, L);
         HIP_TRY(hipGetLastError());
@@ -1685,5 +1713,13 @@ static int status_async(int* err, int32_t* dst_dev, hipStream_t s) {
 }
 extern "C" int parrot_voc_status_async(parrot_voc_t* v, int32_t* dst_dev, void* stream) { return v ? status_async(v->err, dst_dev, (hipStream_t)stream) : PARROT_E_INVALID; }
 extern "C" int parrot_tte_status_async(parrot_tte_t* t, int32_t* dst_dev, void* stream) { return t ? status_async(t->err, dst_dev, (hipStream_t)stream) : PARROT_E_INVALID; }
+// Tie-guard statistics of the last decode, copied to dst_dev[0..2] (device memory) on `stream` without synchronising:
+// {positions whose top-2 logit margin was below the guard, ids changed by the fp64 re-evaluation of the head, the smallest
+// margin of the call as float bits}
+extern "C" int parrot_tte_guard_stats_async(parrot_tte_t* t, int32_t* dst_dev, void* stream) {
+    if (!t || !dst_dev) return fail(PARROT_E_INVALID, "tte_guard_stats: null argument");
+    HIP_TRY(hipMemcpyAsync(dst_dev, t->gstat, 3 * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PARROT_OK;
+}
 extern "C" int parrot_voc_check(parrot_voc_t* v, void* stream) { return v ? read_flag(v->err, (hipStream_t)stream, "vocoder") : PARROT_E_INVALID; }
 extern "C" int parrot_tte_check(parrot_tte_t* t, void* stream) { return t ? read_flag(t->err, (hipStream_t)stream, "tte") : PARROT_E_INVALID; }

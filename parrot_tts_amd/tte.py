@@ -261,6 +261,18 @@ class Parrot(nn.Module):
         r["stages"] = st
         return r
 
+    def guard_stats(self) -> dict:
+        """Tie-guard statistics of the last decode (synchronises): positions whose top-2 logit margin was below the guard
+        (PARROT_TIE_GUARD, default 1e-4) and had their head re-evaluated in fp64, the smallest margin of the call, and how many
+        ids the re-evaluation changed."""
+        import struct
+        dev = self._handle_device
+        buf = torch.zeros(3, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().parrot_tte_guard_stats_async(self._handle, buf.data_ptr(), stream_ptr(dev)))
+        n, changed, bits = (int(v) for v in buf.cpu())
+        return {"n_guarded": n, "min_margin": struct.unpack("f", struct.pack("i", bits))[0], "ids_changed": changed}
+
     def check_outputs(self) -> None:
         """Synchronise and raise FloatingPointError if the last decode produced NaN / inf logits (an activation beyond the
         fp16 split scheme's range; use PARROT_PRECISION=bf16x6 for such a checkpoint), IndexError for a bad id."""

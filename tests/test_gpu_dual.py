@@ -30,7 +30,7 @@ g.check_inputs()
 torch.save(out, {path!r})
 """
 
-SHAPES = [(1, 3), (3, 41), (2, 130), (5, 77)]
+SHAPES = [(1, 3), (3, 41), (2, 130), (5, 77), (40, 64)]  # (the last: more window pairs than CUs -> persistent workgroups loop)
 
 
 def _run(dual, path):
@@ -39,9 +39,10 @@ def _run(dual, path):
     return torch.load(path)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_dual_window_kernels_are_bit_identical_to_the_one_window_kernels(tmp_path, mode):
-    """PARROT_RB_DUAL=1: lean-VALU kernels, one window per workgroup; =2: dual-window anti-phase workgroups; 0: resblock_split.h."""
+    """PARROT_RB_DUAL=1: lean-VALU kernels, one window per workgroup; =2: dual-window anti-phase workgroups; =3: the persistent
+    dual-window kernel (resblock_pdual.h); 0: resblock_split.h."""
     a = _run(mode, str(tmp_path / "dual.pt"))
     b = _run(0, str(tmp_path / "single.pt"))
     for key in a:

@@ -150,3 +150,35 @@ def test_duration_predictor_kernel_other_than_3_is_refused_like_the_reference(tm
     batch = {k: v.to(DEV) for k, v in synth.synth_tte_batch(2, 9, 20, 1, seed=1, ragged=True).items()}
     with pytest.raises(RuntimeError):
         m.eval().to(DEV).infer(batch)
+
+
+def test_tie_guard_reevaluates_low_margin_positions_in_fp64(tmp_path):
+    """VERDICT round 2 item 2.  A head with two IDENTICAL rows makes every position an exact tie in exact arithmetic: torch.argmax
+    (and the oracle) return the first of the two; an fp32 head evaluated in another summation order may not -- the guard's fp64
+    re-evaluation must.  With PARROT_TIE_GUARD=0 the statistics stay empty."""
+    cfg = synth.small_tte_config()
+    cfg["path"]["root_path"] = str(tmp_path)
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({"a": 0, "b": 1}, f)
+    vocab, n_spk = 30, 2
+    sd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=8)
+    hw, hb = sd["head.weight"].clone(), sd["head.bias"].clone()
+    hw[:] = hw * 0.01                       # every other code far below ...
+    hw[17] = hw[5] = torch.randn_like(hw[5])  # ... two identical rows that win everywhere
+    hb[:] = -50.0
+    hb[17] = hb[5] = 3.0
+    sd["head.weight"], sd["head.bias"] = hw, hb
+    m = Parrot(cfg, vocab, 0)
+    m.load_state_dict(sd)
+    m = m.eval().to(DEV)
+    batch = synth.synth_tte_batch(3, 11, vocab, n_spk, seed=2, ragged=True)
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    with torch.no_grad():
+        ref = O.tte_forward(sd, cfg, batch)
+    r = m.infer_dense(gb)
+    gs = m.guard_stats()
+    mask = ref["tgt_mask"]
+    assert gs["n_guarded"] >= int(mask.sum()) and gs["min_margin"] <= 1e-5
+    ids = r["ids"].cpu()
+    assert bool((ids[mask] == 5).all()), "an exact tie goes to the FIRST maximal index (torch.argmax), here code 5"
+    assert torch.equal(ids[mask], torch.argmax(ref["logits"], -1)[mask])
