@@ -790,7 +790,7 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
                 for (int q = 0; q < per_rb; ++q) {
                     const parrot_conv* pc = v->rb[base + q].get();
                     ok = ok && pc->prec == v->scheme && !pc->mfma16 && pc->wfrag16 && pc->nchunks == C / 16 && (C / 32) * pc->n_it16 == steps && pc->M == C &&
-                         tile_cfg(pc->cfg).bm == C;
+                         C % tile_cfg(pc->cfg).bm == 0;  // (whole M-blocks: the stream is [32-row tile][chunk * k + tap] over all C / 32 tiles)
                 }
                 if (!ok) continue;
                 // (the kernel's in-place prefetch after the last tap reads "the next conv's" tap 0 of both chunks: one

@@ -71,16 +71,18 @@ __device__ __forceinline__ void phase_stagger(int units, int first_round) {
 constexpr int RBS_W = 384;  // 32-channel window (the 64-channel kernel uses half: the same 72 KiB of LDS)
 
 // NCH = channel chunks of 16: 2 -> 32 channels, 4 waves side by side (window 384);
-//                              4 -> 64 channels, 2 (row tiles) x 2 (column halves) waves (window 192).
+//                              4 -> 64 channels, 2 (row tiles) x 2 (column halves) waves (window 192);
+//                              8 -> 128 channels, 4 row tiles, one column group (window 96);
+//                             16 -> 256 channels, 8 waves = 8 row tiles, one column group (window 96, 96 KiB of LDS: one workgroup per CU).
 template <class SCH, int NCH>
-__global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock_split_kernel(const ResblockSplitParams p) {
+__global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 3 ? 2 : 3)) void resblock_split_kernel(const ResblockSplitParams p) {
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
-    constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = 4 / WAVES_M, NTW = 3, W = WAVES_N * NTW * 32;
+    constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = (WAVES_M >= 4) ? 1 : 4 / WAVES_M, NTW = 3, W = WAVES_N * NTW * 32;
     const int K = p.k;
     // operand buffer: [piece][chunk][octet][col][8 channels]: 16 bytes per (column, octet), columns contiguous -- both the
     // 16-byte stores of write_p and the ds_read_b128 fragment reads at any tap shift walk consecutive addresses across lanes
     constexpr int OCT_BYTES = W * 16, CH_BYTES = 2 * OCT_BYTES, PIECE_BYTES = NCH * CH_BYTES;
-    static_assert(NCH == 2 || NCH == 4, "32 or 64 channels");
+    static_assert(NCH == 2 || NCH == 4 || NCH == 8 || NCH == 16, "32, 64, 128 channels (4 waves: NCH / 2 row tiles x 4 / (NCH / 2) column groups) or 256 (8 waves)");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // NP * PIECE_BYTES
 
     const int tid = threadIdx.x;
@@ -541,15 +543,16 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
 
 template <class SCH>
 inline hipError_t launch_resblock_split_s(int C, const ResblockSplitParams& p, hipStream_t s) {
-    const size_t lds = (size_t)SCH::NP * 2 * RBS_W * 32;  // the same for every channel count (72 KiB with three pieces)
-    auto kern = (C == 16) ? resblock16_split_kernel<SCH> : (C == 64) ? resblock_split_kernel<SCH, 4> : resblock_split_kernel<SCH, 2>;
-    static DynLdsOnce lds_once[3];
-    const int slot = (C == 16) ? 0 : (C == 64) ? 2 : 1;
+    const size_t lds = (size_t)SCH::NP * 2 * RBS_W * 32 * (C == 256 ? 2 : 1);  // the same up to 128 channels (72 KiB with three pieces)
+    auto kern = (C == 16) ? resblock16_split_kernel<SCH> : (C == 256) ? resblock_split_kernel<SCH, 16> : (C == 128) ? resblock_split_kernel<SCH, 8>
+              : (C == 64) ? resblock_split_kernel<SCH, 4> : resblock_split_kernel<SCH, 2>;
+    static DynLdsOnce lds_once[5];
+    const int slot = (C == 16) ? 0 : (C == 256) ? 4 : (C == 128) ? 3 : (C == 64) ? 2 : 1;
     {
         hipError_t e = ensure_dyn_lds(lds_once[slot], reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(C == 256 ? 512 : 256), lds, s, p);
     return hipGetLastError();
 }
 hipError_t launch_resblock_split_f16x3(int C, const ResblockSplitParams& p, hipStream_t s);   // csrc/tu_resblock.hip
@@ -566,11 +569,19 @@ inline hipError_t launch_resblock_split(int scheme, int C, const ResblockSplitPa
     }
 }
 // odd tap counts with (k + 1) / 2 even; at 64 channels the 192-column window loses too much to the halo of k = 11
+// at 128 channels (window 96) only the k = 3 pairs: the layer kernel is latency-bound there (three MFMA steps per chunk), the
+// fused pair reads x once and writes y once instead of five passes, and a pair's reach (<= 6) leaves >= 87 % of the window
+inline bool resblock_split_wide_k3() {
+    static const bool on = [] { const char* e = getenv("PARROT_RBS_WIDE"); return !e || atoi(e) != 0; }();
+    return on;
+}
 inline bool resblock_split_has(int C, int k) {
+    if (C == 256) return k == 3 && resblock_split_wide_k3();
+    if (C == 128) return k == 3 && resblock_split_wide_k3();
     if (C == 64) return k == 3 || k == 7;
     return (C == 32 || C == 16) && (k == 3 || k == 7 || k == 11);
 }
-inline int resblock_split_window(int C) { return C == 16 ? RBS16_W : C == 64 ? RBS_W / 2 : RBS_W; }
+inline int resblock_split_window(int C) { return C == 16 ? RBS16_W : C >= 128 ? RBS_W / 4 : C == 64 ? RBS_W / 2 : RBS_W; }
 inline int resblock_split_steps(int C, int k) { return C == 16 ? (k + 1) / 2 : (C / 32) * (C / 16) * k; }  // weight steps per conv
 
 }  // namespace parrot
