@@ -20,8 +20,8 @@
 
 namespace parrot {
 
-template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void conv_split16_kernel(const ConvParams p) {
+template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kernel(const ConvParams p) {
     static_assert(K > 0, "tap count is a template parameter");
     constexpr int NPC = SCH::NP, NTERM = SCH::NT;
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
@@ -282,11 +282,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void conv_split16_kernel(
     }
 }
 
-template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K>
+template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
 inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16, COLS = (BN + CONV_HALO + 63) / 64 * 64;
     const size_t lds = (size_t)2 * SCH::NP * 4 * COLS * 16;
-    auto kern = conv_split16_kernel<SCH, WAVES_M, WAVES_N, TM, TN, K>;
+    auto kern = conv_split16_kernel<SCH, WAVES_M, WAVES_N, TM, TN, K, MINW>;
     static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
     {
         hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), (size_t)lds);
@@ -300,14 +300,30 @@ inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
 // tile variants: 0 = 128 x 128 (waves 2x2, wave tile 64x64 = 4x4 MFMA tiles), 1 = 64 x 192 (waves 1x4, wave tile 64x48);
 //                2 = 128 x 64, 3 = 64 x 64: the same row tiling with a third / half of the columns, for launches that would not
 //                    give every CU a workgroup (small batches): the latency of a workgroup is its K loop x MFMAs per step
+// PARROT_S16_M64 (default on; 0: off): the 64-row layers (stage 2, k = 11) on a 64 x 128 tile of 2 x 2 waves (32 x 64 each) at
+// three workgroups per CU instead of 64 x 192 (1 x 4 waves, 64 x 48 each) at two: 2.32 -> 2.21 ms per step
+inline bool split16_m64_small() {
+    static const bool on = [] { const char* e = getenv("PARROT_S16_M64"); return !e || atoi(e) != 0; }();
+    return on;
+}
+// PARROT_S16_N64 (experiment): 128-row layers on 128 x 64 tiles at three workgroups per CU
+inline bool split16_n64_three() {
+    static const bool on = [] { const char* e = getenv("PARROT_S16_N64"); return e && atoi(e) != 0; }();
+    return on;
+}
 inline void split16_tile(int variant, int& bm, int& bn) {
     bm = (variant & 1) ? 64 : 128;
-    bn = variant >= 2 ? 64 : (variant ? 192 : 128);
+    bn = variant >= 2 ? 64 : (variant ? (split16_m64_small() ? 128 : 192) : 128);
 }
 // (k = 3: three steps per 32-channel chunk do not amortise the larger slab -- measured 3-6 % slower than conv_split_kernel)
 inline bool split16_has(int scheme, int k) { return scheme == SchF16x3::ID && (k == 7 || k == 9 || k == 11); }
 template <class SCH>
 inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStream_t s) {
+    if (variant == 2 && split16_n64_three()) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 7, 3>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 11, 3>(p, s);
+            default: break;
+        }
     if (variant == 2) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 7>(p, s);
             case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 9>(p, s);
@@ -320,6 +336,7 @@ inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStr
             case 11: return launch_conv_split16_t<SCH, 1, 4, 4, 1, 11>(p, s);
             default: return hipErrorInvalidValue;
         }
+    if (variant == 1 && split16_m64_small() && p.k == 11) return launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3>(p, s);
     if (variant == 1) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 7>(p, s);
             case 9: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 9>(p, s);
