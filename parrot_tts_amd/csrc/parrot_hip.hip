@@ -1171,7 +1171,10 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
             // (the fused kernels address a batch row with 32-bit byte offsets: rows of 2 GiB and more go layer by layer)
-            if (v->fused != 0 && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
+            // (the 96-column windows of the 128- / 256-channel pair kernel give a short utterance fewer workgroups than the CUs
+            //  there are: small launches stay layer by layer, where the three branches fill the chip together)
+            const bool wide_few = v->chan(i) >= 128 && (long)B * ((T + 83) / 84) < g_num_cus;
+            if (v->fused != 0 && !wide_few && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
                 TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, sj, unit_lens, mul, add, order));
             } else if (resblock_fusable(v, i, j)) {
                 TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, sj, unit_lens, mul, add, order));

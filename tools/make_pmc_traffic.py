@@ -16,10 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def norm(name: str) -> str:
     name = name.replace(" ", "").replace("parrot::", "")
-    m = re.match(r"(conv_split_kernel<Sch\w+,\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
+    m = re.match(r"(conv_split_kernel<Sch\w+,\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?(,(true|false))?>", name)
     if m:
         return m.group(1) + ">"
-    m = re.match(r"(conv_split16_kernel<Sch\w+,\d+,\d+,\d+,\d+),\d+>", name)
+    m = re.match(r"(conv_split16_kernel<Sch\w+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
     if m:
         return m.group(1) + ">"
     if name == "conv1_valu7_vec_kernel":
