@@ -382,14 +382,15 @@ static __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __re
     }
 }
 
-// One workgroup per guarded position: logits[v] = head_b[v] + sum_c head_w[v][c] * x[b][c][t] in fp64 (exact products, one
-// rounding-free sum: the argmax no longer depends on the accumulation order of the head), first maximum wins.
-static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const float* __restrict__ x, const float* __restrict__ hw,
+// One workgroup per guarded position: logits[v] = head_b[v] + sum_c head_w[v][c] * x[b][c][t] in fp64 (exact products, fp64
+// sums in channel order: the argmax no longer depends on the accumulation order of the fp32 head), first maximum wins.
+// `hwt` is the head weight TRANSPOSED to (D, V): thread v reads hwt[c][v], coalesced across the workgroup.
+static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const float* __restrict__ x, const float* __restrict__ hwt,
                                                                       const float* __restrict__ hb, int64_t* __restrict__ ids, int D, int V,
                                                                       int L, const int* __restrict__ glist, int* __restrict__ gstat) {
     const int n = min(gstat[0], TIE_GUARD_MAX);
     if ((int)blockIdx.x >= n) return;
-    extern __shared__ double xs[];  // D activations of the position + the reduction scratch
+    extern __shared__ double xs[];  // D activations of the position
     __shared__ double rv[256];
     __shared__ int ri[256];
     const int b = glist[2 * blockIdx.x], t = glist[2 * blockIdx.x + 1];
@@ -397,11 +398,28 @@ static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const floa
     __syncthreads();
     double best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = threadIdx.x; v < V; v += 256) {
-        const float* w = hw + (size_t)v * D;
-        double acc = hb ? (double)hb[v] : 0.0;
-        for (int c = 0; c < D; ++c) acc = fma((double)w[c], xs[c], acc);
-        if (acc > best) { best = acc; bi = v; }  // (v ascending per thread: the first maximum is kept)
+    for (int v0 = 0; v0 < V; v0 += 1024) {  // four codes per thread and pass: v0 + threadIdx.x + {0, 256, 512, 768}
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        int vv[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vv[q] = v0 + threadIdx.x + 256 * q;
+            ok[q] = vv[q] < V;
+            vv[q] = min(vv[q], V - 1);  // (unconditional loads: a predicated load per element would serialise them; the surplus is ignored below)
+        }
+#pragma unroll 8
+        for (int c = 0; c < D; ++c) {
+            const float* w = hwt + (size_t)c * V;
+            const double xc = xs[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fma((double)w[vv[q]], xc, acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double a = acc[q] + (hb ? (double)hb[vv[q]] : 0.0);
+            if (ok[q] && a > best) { best = a; bi = vv[q]; }  // (codes ascending per thread: the first maximum is kept)
+        }
     }
     rv[threadIdx.x] = best;
     ri[threadIdx.x] = bi;

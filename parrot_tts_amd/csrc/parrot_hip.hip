@@ -1235,7 +1235,7 @@ struct parrot_tte {
     std::vector<float*> dbg_enc, dbg_dec;  // parrot_tte_debug_stages (tests only)
     int scheme = 0;                        // PARROT_PREC_* captured at create
     bool flash = false;                    // attention core on attn_flash_kernel (any T, no score tensor)
-    // tie guard (argmax_cf_kernel / tie_guard_refine_kernel): fp32 head weights for the fp64 re-evaluation, the (b, t) list of
+    // tie guard (argmax_cf_kernel / tie_guard_refine_kernel): fp32 head weights (transposed to (D, V)) for the fp64 re-evaluation, the (b, t) list of
     // the last decode's low-margin positions and its statistics {count, min margin bits, ids changed}
     float *head_w = nullptr, *head_b = nullptr;
     int *glist = nullptr, *gstat = nullptr;
@@ -1350,7 +1350,12 @@ extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, 
     {   // tie guard: PARROT_TIE_GUARD = margin below which a position's head is re-evaluated in fp64 (0 switches it off)
         const char* e = getenv("PARROT_TIE_GUARD");
         t->guard = e ? (float)atof(e) : 1e-4f;
-        TRY(upload(&t->head_w, w->head_w, (size_t)c.n_codes * D));
+        {   // (D, V): the refine kernel reads one code per thread, coalesced
+            std::vector<float> wt((size_t)c.n_codes * D);
+            for (int v = 0; v < c.n_codes; ++v)
+                for (int ch = 0; ch < D; ++ch) wt[(size_t)ch * c.n_codes + v] = w->head_w[(size_t)v * D + ch];
+            TRY(upload(&t->head_w, wt.data(), wt.size()));
+        }
         if (w->head_b) TRY(upload(&t->head_b, w->head_b, (size_t)c.n_codes));
         HIP_TRY(hipMalloc((void**)&t->glist, 2 * TIE_GUARD_MAX * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&t->gstat, 4 * sizeof(int)));
