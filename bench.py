@@ -237,6 +237,27 @@ def main():
             if n > 0:
                 rows.append({"kernel": nm, "launches_per_step": n / steps, "avg_us": tms / n * 1e3, "ms_per_step": tms / steps,
                              "tflops": fl / tms / 1e9, "alg_gbs": by / tms / 1e6})
+        # per row: fraction of the scheme's MFMA roof and of the 8 TB/s HBM peak (algorithmic bytes), and which resource binds the
+        # kernel as measured (counters, phase traces, instruction probes)
+        n_mf = SCHEMES[precision][1]
+        for r in rows:
+            k = r["kernel"]
+            split_k = "_split" in k
+            r["frac_of_mfma_roof"] = r["tflops"] / ((MFMA16_PEAK_TFLOPS / n_mf) if split_k else FP32_MFMA_PEAK_TFLOPS)
+            r["frac_of_hbm_peak"] = r["alg_gbs"] / HBM_PEAK_GBS
+            if "valu_kernel" in k:
+                r["bound"] = "hbm (fp32 FMA streaming kernel; 6.3 TB/s achievable)"
+            elif k.startswith("resblock"):
+                r["bound"] = ("operand conversion: scale / leaky ReLU / fp16 hi-lo split / LDS store of every conv input is VALU work of the same "
+                              "order as the conv's MFMAs (2.2-3.8 k clocks vs 1.2-6.3 k per lane and conv), and VALU beside MFMA costs 2-3x")
+            elif k.startswith("conv_split16"):
+                r["bound"] = "mfma 16-bit (power-limited clock); short-K layers (64 / 128 channels) add exposed prologue / epilogue latency"
+            elif "2,2,2,1,3" in k:
+                r["bound"] = "latency: 27 launches of 13-50 us (1x1 convs of the TTE, K = 256 ... 1024)"
+            elif k.startswith("conv_split"):
+                r["bound"] = "mfma 16-bit with 27-33 % zero polyphase taps (transposed convs) + HBM (2-3 TB/s algorithmic)"
+            else:
+                r["bound"] = "mfma fp32"
         rows.sort(key=lambda r: -r["ms_per_step"])
         n_samples = world * B * (wav.shape[-1] if wav is not None else 4 * S * 320)
         del pipe, parrot, gen
