@@ -28,6 +28,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t valu_row_rsrc(const float* bas
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 }
 
+// Linear(C -> 1) over (B, C, T) (the duration predictor's projection, reference modules/duration.py:39): lane = time step
+// (coalesced 256-byte rows), the four waves of a workgroup take a quarter of the channels each and their partial sums are added
+// in wave order; the generic kernel below gives a short sequence (S = 64) sixteen busy threads with 256-deep load chains (76 us).
+__global__ __launch_bounds__(256) void linear1_valu_kernel(const ConvValuParams p) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + lane;
+    const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;
+    const __amdgpu_buffer_rsrc_t xr = valu_row_rsrc(p.x + (size_t)b * p.Cin * p.Tin);
+    const int voff = (t < Tlim) ? t * 4 : (int)0x80000000;
+    const int per = (p.Cin + 3) / 4, c0 = wave * per, c1 = min(p.Cin, c0 + per);
+    const int row_bytes = p.Tin * 4;
+    float acc = 0.f;
+    for (int c = c0; c < c1; ++c) {
+        const float xv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff, c * row_bytes, 0));
+        acc = fmaf(p.w[c], fmaxf(xv, xv * p.slope), acc);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && t < p.Tout) {
+        const float v = (((p.bias ? p.bias[0] : 0.f) + part[0][lane]) + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (p.act == ACT_TANH && p.err && !(fabsf(v) < INFINITY)) atomicExch(p.err, 5);
+        p.y[(size_t)b * p.Tout + t] = (p.act == ACT_TANH) ? tanhf(v) : v;
+    }
+}
+
 // Conv1d with ONE output channel, dilation 1, padding (K-1)/2: four consecutive outputs per thread.
 template <int K>
 __global__ __launch_bounds__(256) void conv1_valu_kernel(const ConvValuParams p) {

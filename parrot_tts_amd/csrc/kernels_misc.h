@@ -324,18 +324,19 @@ static __global__ __launch_bounds__(256) void length_regulate_kernel(const float
 // gstat[0], the smallest margin of the call lands in gstat[2] (float bits; positive floats order like ints) --
 // tie_guard_refine_kernel then re-evaluates the head for exactly those positions in fp64.
 constexpr int TIE_GUARD_MAX = 256;
-static __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L,
+constexpr int ARGMAX_WAVES = 16;  // waves per 64 positions: 62-63 codes each at V = 1000 (sixteen loads in flight per position)
+static __global__ __launch_bounds__(64 * ARGMAX_WAVES) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L,
                                                                int* __restrict__ err, float guard, int* __restrict__ glist,
                                                                int* __restrict__ gstat) {
-    // lane = time step; the four waves scan a quarter of the vocabulary each, then the first maximum wins
+    // lane = time step; the waves scan a slice of the vocabulary each, then the first maximum wins
     // (strict > inside a range, lower range first on ties: torch.argmax's first-occurrence rule)
-    __shared__ float bv[4][64], sv[4][64];
-    __shared__ int bix[4][64], bad[4][64];
+    __shared__ float bv[ARGMAX_WAVES][64], sv[ARGMAX_WAVES][64];
+    __shared__ int bix[ARGMAX_WAVES][64], bad[ARGMAX_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int t = blockIdx.x * 64 + lane;
     const bool ok = t < L;
-    const int per = (V + 3) / 4, v0 = wave * per, v1 = min(V, v0 + per);
+    const int per = (V + ARGMAX_WAVES - 1) / ARGMAX_WAVES, v0 = wave * per, v1 = min(V, v0 + per);
     const float* lb = logits + (size_t)b * V * L + (ok ? t : 0);
     float best = -INFINITY, second = -INFINITY;  // second: the largest value of the range that is not `best`'s element
     int bi = v0 < V ? v0 : 0, nonfinite = 0;
@@ -363,7 +364,7 @@ static __global__ __launch_bounds__(256) void argmax_cf_kernel(const float* __re
         float m = bv[0][lane], s2 = sv[0][lane];
         int mi = bix[0][lane], nf = bad[0][lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < ARGMAX_WAVES; ++w) {
             const float bw = bv[w][lane];
             nf |= bad[w][lane];
             if (bw > m) { s2 = fmaxf(fmaxf(s2, m), sv[w][lane]); m = bw; mi = bix[w][lane]; }

@@ -495,7 +495,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         if (c->valu_kind == 1 && c->d.k == 7 && (Tin & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0)
             hipLaunchKernelGGL(conv1_valu7_vec_kernel, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
         else if (c->valu_kind == 1 && c->d.k == 7) hipLaunchKernelGGL(conv1_valu_kernel<7>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
-        else if (c->valu_kind == 1) hipLaunchKernelGGL(conv1_valu_kernel<1>, dim3((Tout + 1023) / 1024, B), dim3(256), 0, s, q);
+        else if (c->valu_kind == 1) hipLaunchKernelGGL(linear1_valu_kernel, dim3((Tout + 63) / 64, B), dim3(256), 0, s, q);
         else hipLaunchKernelGGL((convt_valu_kernel<16, 4, 2, 1>), dim3((Tin + 255) / 256, B), dim3(256), 0, s, q);
         HIP_TRY(hipGetLastError());
         if (g_prof_on) TRY(prof_close(rec, s));
@@ -1171,10 +1171,10 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
             // (the fused kernels address a batch row with 32-bit byte offsets: rows of 2 GiB and more go layer by layer)
-            // (the 96-column windows of the 128- / 256-channel pair kernel give a short utterance fewer workgroups than the CUs
-            //  there are: small launches stay layer by layer, where the three branches fill the chip together)
-            const bool wide_few = v->chan(i) >= 128 && (long)B * ((T + 83) / 84) < g_num_cus;
-            if (v->fused != 0 && !wide_few && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
+            // (which kernel family runs a block never depends on the batch size or on the launch size: row b of a batch must equal
+            //  the same utterance run alone BIT FOR BIT -- the batched driver's byte-identical WAVs rest on it.  At B = 1 the
+            //  96-column windows of the 128- / 256-channel pair kernels are only 16-61 workgroups: 3.4 instead of 3.2 ms per utterance)
+            if (v->fused != 0 && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
                 TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, sj, unit_lens, mul, add, order));
             } else if (resblock_fusable(v, i, j)) {
                 TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, sj, unit_lens, mul, add, order));
@@ -1564,7 +1564,7 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
     TRY(conv_launch(t->head.get(), w.x, nullptr, w.logits, B, L, EPI_STORE, 1.f, 0, 0, 0, s));
     {   // argmax + tie guard: gstat = {count, ids changed, min margin (float bits)} of this decode
         const bool on = t->guard > 0.f;  // (length_regulate_kernel, the first kernel of this decode, has reset gstat)
-        hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, w.logits, ids, V, L, t->err, t->guard,
+        hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(64 * ARGMAX_WAVES), 0, s, w.logits, ids, V, L, t->err, t->guard,
                            on ? t->glist : nullptr, on ? t->gstat : nullptr);
         HIP_TRY(hipGetLastError());
         if (on) {  // re-evaluate the head of the low-margin positions in fp64 (workgroups beyond the count exit at once)
