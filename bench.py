@@ -101,12 +101,33 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the scheduler affinity, cut to the cgroup CPU quota when one is set
+    (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us).  The GPU boxes show 256 logical CPUs under a 16-CPU quota:
+    threads beyond the quota are throttled, not run (profiles/r03_cpu_thread_sweep.jsonl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(cfg, h, tsd, vsd, B, S, vocab, n_spk):
     """The oracle (CPU restatement, parity-pinned to the reference) timed on this host's cores on a bounded
     sample of the same workload: B utterances of the full pipeline."""
     from oracle import parrot_oracle as O
-    # more threads than ~64 only adds oversubscription on these layer sizes (256 threads: 100 s / pass)
-    cores = min(physical_cores(), 64)
+    # every CPU the process is allowed (affinity and cgroup quota), up to 64: beyond ~64 threads these layer sizes only
+    # oversubscribe (256 threads: 100 s / pass), and threads beyond a cgroup quota are throttled
+    cores = min(physical_cores(), cpu_quota(), 64)
     torch.set_num_threads(cores)
     batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=0)
     folded = O.fold_weight_norm(vsd)
@@ -126,6 +147,7 @@ def cpu_baseline(cfg, h, tsd, vsd, B, S, vocab, n_spk):
     best = min(ts)
     n = y.shape[0] * y.shape[-1]
     return {"value": n / best, "unit": "samples/s", "cores": cores, "host_physical_cores": physical_cores(), "host_logical_cpus": os.cpu_count(),
+            "host_cpu_quota": cpu_quota(),
             "kind": "port",
             "sample": f"oracle full pipeline (TTE S={S}->L={y.shape[-1] // 320} + HiFi-GAN), batch {B}, fp32, torch-CPU {cores} threads, "
                       f"best of 2 after 1 warm-up ({best:.2f} s/pass)",
