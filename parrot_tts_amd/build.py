@@ -14,6 +14,12 @@ OBJ = os.path.join(HERE, "build")
 SOURCES = ["parrot_hip.hip"] + sorted(f for f in os.listdir(CSRC) if f.startswith("tu_") and f.endswith(".hip"))
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "parrot_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# Per-source flags.  tu_split16: LLVM's machine-sink pass moves the weight refills for the next chunk's first k-step -- which feed
+# nothing but loop-carried registers -- out of the MFMA block into the loop latch, behind the slab conversion and the barrier, so
+# that the first step of every chunk waits a full fetch latency (tools/isa_schedule.py shows it in the ISA).  Without the pass
+# they stay where they are written: conv_split16 128 x 128: 6.88 -> 6.78 ms per step (mean of five same-box A/B pairs, the
+# sign held in four, one tie: at the edge of the run-to-run noise), no spills, nothing else moves.
+TU_FLAGS = {"tu_split16.hip": ["-mllvm", "-disable-machine-sink"]}
 
 
 def _stale() -> bool:
@@ -34,7 +40,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: 
 
     def compile_one(src):
         obj = os.path.join(OBJ_OUT, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        tu = [] if os.environ.get("PARROT_NO_TU_FLAGS") else TU_FLAGS.get(src, [])  # (A/B builds: tools/build_exp.sh)
+        cmd = [hipcc] + FLAGS + tu + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True, cwd=CSRC)

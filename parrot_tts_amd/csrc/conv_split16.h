@@ -20,6 +20,23 @@
 
 namespace parrot {
 
+#ifdef S16_TRACE
+// experiment builds only (tools/build_exp.sh s16trace -DS16_TRACE; tools/s16_trace.py): shader-clock marks of workgroup 0's waves --
+// [wave][0] start, [1] first slab staged, [2 + c] chunk c done, then epilogue done; [wave][62] / [63]: 100 MHz real-time clock
+__device__ unsigned long long g_s16_trace[4 * 64];
+#define S16_MARK(i)                                                                                                 \
+    do {                                                                                                            \
+        if (blockIdx.x == 0 && lane == 0 && (i) < 62) g_s16_trace[wave * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define S16_REAL(i)                                                                                         \
+    do {                                                                                                    \
+        if (blockIdx.x == 0 && lane == 0) g_s16_trace[wave * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define S16_MARK(i) do { } while (0)
+#define S16_REAL(i) do { } while (0)
+#endif
+
 template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kernel(const ConvParams p) {
     static_assert(K > 0, "tap count is a template parameter");
@@ -48,6 +65,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     const int mblock = seq % n_mb;
     const int tile_id = xcd * tpx + seq / n_mb;
     if (tile_id >= n_tiles || seq / n_mb >= tpx) return;
+    S16_REAL(62);
+    S16_MARK(0);
     const int b = tile_id / p.tiles_n;
     const int tn0 = tile_id - b * p.tiles_n;
     const int t0 = tn0 * BN;
@@ -175,6 +194,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     load_slab(0);
     store_slab(0);
     __syncthreads();
+    S16_MARK(1);
 
     for (int c = 0; c < nchunks; ++c) {  // one chunk = K straight-line steps
         const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
@@ -191,7 +211,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         acc[tm][tn] = mfma16<SCH>(A[tm][SCH::pa(t)], Bv[tn][SCH::pb(t)], acc[tm][tn]);
+#ifndef EXP_S16_NO_BRELOAD  // (timing ablation: the step's fragments are not re-read)
                         if (tm == TM - 1 && t == NTERM - 1 && j + 1 < K) load_b_tile(Bv[tn], xs, tn, j + 1);
+#endif
                     }
                 load_a_tile(A[tm], tm, c * K + j + 1);  // (past the last step: the stream is padded by one step)
             }
@@ -222,8 +244,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifndef EXP_S16_NO_STORE  // (timing ablation: no conversion, no LDS stores)
         if (more) store_slab((c + 1) & 1);
+#endif
         __syncthreads();
+        S16_MARK(2 + c);
     }
 
     // ---- epilogue (plain convs only): scale back, late residual / activation / MRF accumulation modes ------------------
@@ -280,6 +305,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
 #pragma unroll
             for (int r = 0; r < 4; ++r) row_tile_store(yt, v[tn][r], vo[tn], (m0 + r) * out_row_bytes);
     }
+    S16_MARK(2 + nchunks);
+    S16_REAL(63);
 }
 
 template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
