@@ -24,17 +24,37 @@ namespace parrot {
 // experiment builds only (tools/build_exp.sh s16trace -DS16_TRACE; tools/s16_trace.py): shader-clock marks of workgroup 0's waves --
 // [wave][0] start, [1] first slab staged, [2 + c] chunk c done, then epilogue done; [wave][62] / [63]: 100 MHz real-time clock
 __device__ unsigned long long g_s16_trace[4 * 64];
+// ... and one record per workgroup of the launch: {start, end (100 MHz real-time clock), HW_ID, XCC_ID} (tools/s16_launch_timeline.py)
+constexpr int S16_WG_MAX = 16384;
+__device__ unsigned long long g_s16_wg[S16_WG_MAX * 4];
+#define S16_WG_BEGIN()                                                                     \
+    do {                                                                                   \
+        if (tid == 0 && vb < S16_WG_MAX) {                                         \
+            unsigned hwid, xcc;                                                            \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));             \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));             \
+            g_s16_wg[vb * 4 + 0] = __builtin_amdgcn_s_memrealtime();               \
+            g_s16_wg[vb * 4 + 2] = hwid;                                           \
+            g_s16_wg[vb * 4 + 3] = xcc;                                            \
+        }                                                                                  \
+    } while (0)
+#define S16_WG_END()                                                                                             \
+    do {                                                                                                         \
+        if (tid == 0 && vb < S16_WG_MAX) g_s16_wg[vb * 4 + 1] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #define S16_MARK(i)                                                                                                 \
     do {                                                                                                            \
-        if (blockIdx.x == 0 && lane == 0 && (i) < 62) g_s16_trace[wave * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if (vb == 0 && lane == 0 && (i) < 62) g_s16_trace[wave * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #define S16_REAL(i)                                                                                         \
     do {                                                                                                    \
-        if (blockIdx.x == 0 && lane == 0) g_s16_trace[wave * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if (vb == 0 && lane == 0) g_s16_trace[wave * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define S16_MARK(i) do { } while (0)
 #define S16_REAL(i) do { } while (0)
+#define S16_WG_BEGIN() do { } while (0)
+#define S16_WG_END() do { } while (0)
 #endif
 
 template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
@@ -61,12 +81,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     // XCD-aware block order (see conv_split.h): a contiguous run of column tiles per XCD, M-blocks back to back
     const int n_mb = (p.M + BM - 1) / BM;
     const int n_tiles = p.tiles_n * p.B, tpx = (n_tiles + 7) >> 3;  // column tiles per XCD
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;          // (workgroup id i runs on XCD i % 8, in id order)
+    const int vb = blockIdx.x;
+    const int xcd = vb & 7, seq = vb >> 3;  // (workgroup id i runs on XCD i % 8, in id order)
     const int mblock = seq % n_mb;
     const int tile_id = xcd * tpx + seq / n_mb;
     if (tile_id >= n_tiles || seq / n_mb >= tpx) return;
     S16_REAL(62);
     S16_MARK(0);
+    S16_WG_BEGIN();
     const int b = tile_id / p.tiles_n;
     const int tn0 = tile_id - b * p.tiles_n;
     const int t0 = tn0 * BN;
@@ -196,7 +218,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     __syncthreads();
     S16_MARK(1);
 
+    // Wave priority by progress (p.prio): two workgroups share a CU and the SIMD arbiter serves the OLDER wave first, so of two
+    // workgroups started together one finishes after ~0.8 and the other after ~1.2 workgroup times (tools/s16_launch_timeline.py)
+    // and the launch ends with one workgroup per CU.  A wave that is further into its K loop yields to one that is behind.
+    const bool prio_on = p.prio == 1 || (p.prio == 2 && vb + 2 * p.n_cus >= (int)gridDim.x);
     for (int c = 0; c < nchunks; ++c) {  // one chunk = K straight-line steps
+        if (prio_on) {
+            const int q = c * 4 / nchunks;
+            if (q == 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
         const bool more = c + 1 < nchunks;
         if (more) load_slab(c + 1);
@@ -307,6 +340,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     }
     S16_MARK(2 + nchunks);
     S16_REAL(63);
+    S16_WG_END();
 }
 
 template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
@@ -338,14 +372,35 @@ inline bool split16_n64_three() {
     static const bool on = [] { const char* e = getenv("PARROT_S16_N64"); return e && atoi(e) != 0; }();
     return on;
 }
+//                4 = 128 x 160 (waves 2x2, wave tile 64x80): for launches whose 128-column tiling ends in a half-empty round
+//                    (split16_wide_fits below)
 inline void split16_tile(int variant, int& bm, int& bn) {
     bm = (variant & 1) ? 64 : 128;
-    bn = variant >= 2 ? 64 : (variant ? (split16_m64_small() ? 128 : 192) : 128);
+    bn = variant == 4 ? 160 : variant >= 2 ? 64 : (variant ? (split16_m64_small() ? 128 : 192) : 128);
+}
+// Two 128-row workgroups fit a CU, so a launch runs in rounds of 2 x CUs workgroups, and a workgroup takes the same time whether
+// its CU is shared or not (tools/s16_launch_timeline.py): stage 0 at B = 64 is 1280 tiles of 128 x 128 = 2.5 rounds, the last one
+// with half of the slots empty.  The same layer on 128 x 160 tiles is 1024 workgroups = 2 full rounds of 1.25x the work each.
+// Rule: rounds x tile width, 160 only when it wins by more than 3 %.  (Tile shapes never change the arithmetic of an output.)
+// PARROT_S16_N160 (default on; 0: off)
+inline bool split16_wide_fits(long ncols, long rows, int n_mb, int n_cus) {
+    static const bool on = [] { const char* e = getenv("PARROT_S16_N160"); return !e || atoi(e) != 0; }();
+    if (!on) return false;
+    const long slots = 2L * n_cus;
+    const long wg128 = (ncols + 127) / 128 * rows * n_mb, wg160 = (ncols + 159) / 160 * rows * n_mb;
+    const long cost128 = (wg128 + slots - 1) / slots * 128, cost160 = (wg160 + slots - 1) / slots * 160;
+    return cost160 * 100 < cost128 * 97;
 }
 // (k = 3: three steps per 32-channel chunk do not amortise the larger slab -- measured 3-6 % slower than conv_split_kernel)
 inline bool split16_has(int scheme, int k) { return scheme == SchF16x3::ID && (k == 7 || k == 9 || k == 11); }
 template <class SCH>
 inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStream_t s) {
+    if (variant == 4) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 7>(p, s);
+            case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 9>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 11>(p, s);
+            default: return hipErrorInvalidValue;
+        }
     if (variant == 2 && split16_n64_three()) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 7, 3>(p, s);
             case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 11, 3>(p, s);

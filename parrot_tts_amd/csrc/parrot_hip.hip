@@ -517,6 +517,10 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         static const int lean = [] { const char* e = getenv("PARROT_LEAN_EPI"); return e ? atoi(e) : 1; }();
         p.lean = lean;
     }
+    {   // PARROT_S16_PRIO (conv_split16_kernel): progress-based wave priorities, 0 off / 1 every workgroup / 2 last round only
+        static const int prio = [] { const char* e = getenv("PARROT_S16_PRIO"); return e ? atoi(e) : 0; }();
+        p.prio = prio; p.n_cus = g_num_cus;
+    }
     p.fold_res = c->late_res ? 0 : 1;
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
@@ -541,6 +545,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         // a half / third of the MFMAs per step: the per-launch latency is what counts there, not the operand reuse)
         if (small_tiles && (long)((p.Ncols + t.bn - 1) / t.bn) * B * ((c->M + t.bm - 1) / t.bm) < g_num_cus) variant16 += 2;
         else if (variant16 == 0 && c->M == 128 && split16_n64_three()) variant16 = 2;  // (experiment: 128 x 64 tiles, three workgroups per CU)
+        else if (variant16 == 0 && split16_wide_fits(p.Ncols, B, (c->M + 127) / 128, g_num_cus)) variant16 = 4;  // 128 x 160: no half-empty last round
         split16_tile(variant16, t.bm, t.bn);
     } else if (c->prec >= 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
@@ -556,7 +561,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         // algorithmic work of the layer (real taps only; DESIGN.md "roofline accounting")
         const double macs = (double)B * c->d.c_out * c->Cin * c->d.k * (c->d.transposed ? (double)Tin : (double)Tout);
         const double elems = (double)B * ((double)c->d.c_in * Tin + (double)c->Cout * Tout * (1 + (res ? 1 : 0) + (epi != EPI_STORE ? 1 : 0)));
-        const int row = c->mfma16 ? NUM_TILE_CFGS + 9 + (variant16 & 1)
+        const int row = c->mfma16 ? (variant16 == 4 ? NUM_TILE_CFGS + 12 : NUM_TILE_CFGS + 9 + (variant16 & 1))
                                   : (c->prec >= 1) ? (variant16 >= 2 ? NUM_TILE_CFGS + 1 + variant16 : NUM_TILE_CFGS + cfg) : cfg;  // split rows follow the exact ones
         TRY(prof_open(rec, row, 2.0 * macs, 4.0 * (elems + (double)c->d.c_out * c->Cin * c->d.k), s));
     }
@@ -970,7 +975,9 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         const double macs = (double)B * C * C * k * T * (m1 - m0);
         if (last && before_last) HIP_TRY(hipStreamWaitEvent(s, before_last, 0));  // the MRF sum is accumulated in branch order
         const bool k16 = v->rb_kind[(size_t)stage * c.n_kernels + j] == 1;
-        if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 16 ? 6 : k16 ? 11 : 5), 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
+        // rows: one per kernel instantiation (C = 32 / 64 / 128 / 256 are resblock_split_kernel<SCH, 2 / 4 / 8 / 16>)
+        const int prow = C == 16 ? 6 : k16 ? 11 : C == 32 ? 5 : C == 64 ? 13 : C == 128 ? 14 : 15;
+        if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + prow, 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
         // PARROT_RB_DUAL (experiments, resblock_dual.h; measured slower): 0 (default) the kernels of
         // resblock_split.h, 1 the lean-VALU variant with one window per workgroup, 2 dual-window anti-phase workgroups
         static const int dual_mode = [] { const char* e = getenv("PARROT_RB_DUAL"); return e ? atoi(e) : 0; }();

@@ -10,4 +10,12 @@ hipError_t launch_resblock_split16_f16x3(int C, const ResblockSplitParams& p, hi
 extern "C" int parrot_debug_s16_trace(unsigned long long* out_host) {
     return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(parrot::g_s16_trace), sizeof(unsigned long long) * 4 * 64);
 }
+extern "C" int parrot_debug_s16_wg(unsigned long long* out_host, int n_wg) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(parrot::g_s16_wg), sizeof(unsigned long long) * 4 * (n_wg < parrot::S16_WG_MAX ? n_wg : parrot::S16_WG_MAX));
+}
+extern "C" int parrot_debug_s16_wg_clear() { 
+    static unsigned long long zeros[parrot::S16_WG_MAX * 4];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(parrot::g_s16_wg), zeros, sizeof zeros);
+}
 #endif
