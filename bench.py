@@ -40,7 +40,8 @@ SAMPLE_RATE = 16000             # reference utils/vocoder/config.json:32 (the me
 TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>", "conv_mfma_kernel<1,4,1,4,16,2>",
               "conv_mfma_kernel<2,2,2,2,32,3>", "conv_mfma_kernel<2,2,2,1,16,3>", "conv_mfma_kernel<1,4,1,2,16,4>",
               "conv_mfma16_kernel<8,2>", "conv_split_kernel<SCH,2,2,2,2,2>", "conv_split_kernel<SCH,1,4,2,2,2>", "resblock_fused16_kernel",
-              "conv_split_kernel<SCH,2,2,2,1,3>", "conv_split_kernel<SCH,1,4,1,4,2>", "resblock_split_kernel<SCH,2>", "resblock16_split_kernel<SCH>",
+              "conv_split_kernel<SCH,4,1,1,2,3>" if os.environ.get("PARROT_SPLIT_WN1", "1") != "0" else "conv_split_kernel<SCH,2,2,2,1,3>",  # the 128 x 64 tile
+              "conv_split_kernel<SCH,1,4,1,4,2>", "resblock_split_kernel<SCH,2>", "resblock16_split_kernel<SCH>",
               "conv1_valu_kernel", "convt_valu_kernel<16,4,2,1>", "conv_split16_kernel<SCH,2,2,4,4>",
               "conv_split16_kernel<SCH,2,2,2,4>" if os.environ.get("PARROT_S16_M64", "1") != "0" else "conv_split16_kernel<SCH,1,4,4,3>",  # the 64-row tile
               "resblock_split16_kernel<SCH>", "conv_split16_kernel<SCH,2,2,4,5>",
@@ -275,7 +276,7 @@ def main():
                               "order as the conv's MFMAs (2.2-3.8 k clocks vs 1.2-6.3 k per lane and conv), and VALU beside MFMA costs 2-3x")
             elif k.startswith("conv_split16"):
                 r["bound"] = "mfma 16-bit (power-limited clock); short-K layers (64 / 128 channels) add exposed prologue / epilogue latency"
-            elif "2,2,2,1,3" in k:
+            elif "2,2,2,1,3" in k or "4,1,1,2,3" in k:
                 r["bound"] = "latency: 27 launches of 13-50 us (1x1 convs of the TTE, K = 256 ... 1024)"
             elif k.startswith("conv_split"):
                 r["bound"] = "mfma 16-bit with 27-33 % zero polyphase taps (transposed convs) + HBM (2-3 TB/s algorithmic)"

@@ -486,6 +486,13 @@ inline unsigned split_grid(const ConvParams& p, int bm) {  // 1-D: 8 XCDs x ceil
     const unsigned tiles = (unsigned)p.tiles_n * p.B, n_mb = (p.M + bm - 1) / bm;
     return (tiles + 7) / 8 * 8 * n_mb;
 }
+// PARROT_SPLIT_WN1 (default on; 0: the 2 x 2 wave grid): the 128 x 64 tile (1x1 convs, short sequences) with its four waves stacked
+// along M, each covering all 64 columns: every weight fragment is fetched by one wave instead of two (the vector L1 delivers
+// 64 B/clk, LDS 128 B/clk).  TTE 1x1 convs at B = 64: 0.77 -> 0.70 ms per step; one utterance: 0.55 -> 0.51 ms.
+inline bool split_wn1() {
+    static const bool on = [] { const char* e = getenv("PARROT_SPLIT_WN1"); return !e || atoi(e) != 0; }();
+    return on;
+}
 inline bool split_k3_subs2() {
     // (measured +-0: the k = 3 layers of stages 0-1 move 2-3 TB/s of algorithmic bytes -- they are HBM-bound, not barrier-bound)
     static const bool on = [] { const char* e = getenv("PARROT_K3_SUBS"); return e && atoi(e) != 0; }();
@@ -499,6 +506,16 @@ inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStrea
     dim3 grid(split_grid(p, bm));
     if (variant == 3) return p.k == 3 ? launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 3>(p, grid, s) : launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 0>(p, grid, s);
     const bool lean = conv_lean_ok(p);  // plain conv: the instantiation with the buffer-addressed prologue / epilogue
+    if (variant == 2 && split_wn1()) {  // the 128 x 64 tile with its four waves stacked along M (see conv_split16.h, PARROT_S16_WN1)
+        if (p.k == 1 && p.nchunks % 4 == 0)
+            return lean ? launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 1, 4, true>(p, grid, s) : launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 1, 4>(p, grid, s);
+        switch (p.k) {
+            case 1: return launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 1>(p, grid, s);
+            case 3: return launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 3>(p, grid, s);
+            case 9: return launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 9>(p, grid, s);
+            default: return launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 0>(p, grid, s);
+        }
+    }
     if (variant == 2) {
         if (p.k == 1 && p.nchunks % 4 == 0)  // 64 channels per barrier
             return lean ? launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4, true>(p, grid, s) : launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4>(p, grid, s);

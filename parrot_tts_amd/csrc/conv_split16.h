@@ -374,6 +374,10 @@ inline bool split16_n64_three() {
 }
 //                4 = 128 x 160 (waves 2x2, wave tile 64x80): for launches whose 128-column tiling ends in a half-empty round
 //                    (split16_wide_fits below)
+inline int split16_wn1() {
+    static const int v = [] { const char* e = getenv("PARROT_S16_WN1"); return e ? atoi(e) : 2; }();
+    return v;
+}
 inline void split16_tile(int variant, int& bm, int& bn) {
     bm = (variant & 1) ? 64 : 128;
     bn = variant == 4 ? 160 : variant >= 2 ? 64 : (variant ? (split16_m64_small() ? 128 : 192) : 128);
@@ -405,6 +409,31 @@ inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStr
             case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 7, 3>(p, s);
             case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 11, 3>(p, s);
             default: break;
+        }
+    // The small tiles run alone on their CU and stream their weights from L2 through the vector L1 at 64 B/clk: with the 2 x 2
+    // wave grid both column waves fetch the same row fragments -- 360 KB per 32-channel chunk at k = 11 = 5.6 k clocks against
+    // 4.5 k of MFMA (tools/s16_trace.py).  Waves stacked along M only (4 x 1, each wave all 64 columns) fetch every weight
+    // fragment once (2.8 k clocks) and read more LDS fragments instead (128 B/clk).  One utterance, stage 0, k = 11: 32.8 -> 26.2 us
+    // per launch (8 x 1 waves), FFN conv 35.0 -> 24.8, stage 2 (64 x 64 tile, 4 x 1) 19.1 -> 11.2; B = 1 3.11 -> 2.90 ms, B = 4
+    // 3.85 -> 3.62 ms.  PARROT_S16_WN1: 2 (default) eight waves on the 128-row tile / four on the 64-row one, 1 four waves on
+    // both, 0 the 2 x 2 / 1 x 4 grids.
+    if (variant == 2 && split16_wn1() == 2) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 7, 1>(p, s);
+            case 9: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 9, 1>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 11, 1>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    if (variant == 2 && split16_wn1()) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 4, 1, 2, 4, 7>(p, s);
+            case 9: return launch_conv_split16_t<SCH, 4, 1, 2, 4, 9>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 4, 1, 2, 4, 11>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    if (variant == 3 && split16_wn1()) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 7>(p, s);
+            case 9: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 9>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 11>(p, s);
+            default: return hipErrorInvalidValue;
         }
     if (variant == 2) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 7>(p, s);

@@ -201,7 +201,7 @@ def test_profile_kernel_names_fold_to_bench_rows():
     spec.loader.exec_module(mod)
     import bench
     cases = {"conv_split_kernel<parrot::SchF16x3, 2, 2, 2, 2, 2, 11, 1>": "conv_split_kernel<SchF16x3,2,2,2,2,2>",
-             "conv_split_kernel<parrot::SchF16x3, 2, 2, 2, 1, 3, 1, 4>": "conv_split_kernel<SchF16x3,2,2,2,1,3>",
+             "conv_split_kernel<parrot::SchF16x3, 4, 1, 1, 2, 3, 1, 4, true>": "conv_split_kernel<SchF16x3,4,1,1,2,3>",
              "conv_split_kernel<parrot::SchF16x3, 1, 4, 1, 4, 2, 3, 1>": "conv_split_kernel<SchF16x3,1,4,1,4,2>",
              "resblock_split_kernel<parrot::SchF16x3, 4>": "resblock_split_kernel<SchF16x3,4>",
              "resblock_split_kernel<parrot::SchF16x3, 16>": "resblock_split_kernel<SchF16x3,16>",
