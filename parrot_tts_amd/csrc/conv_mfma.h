@@ -578,6 +578,8 @@ inline hipError_t launch_conv_t(const ConvParams& p, dim3 grid, size_t lds, hipS
     return hipGetLastError();
 }
 
+// (a template so that the six kernels are instantiated only in the translation unit that calls it, not in every one that includes this header)
+template <class = void>
 inline hipError_t launch_conv(int cfg, const ConvParams& p, hipStream_t s) {
     const TileCfg t = tile_cfg(cfg);
     dim3 grid(p.tiles_n * p.B, (p.M + t.bm - 1) / t.bm);

@@ -506,7 +506,7 @@ inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStrea
     dim3 grid(split_grid(p, bm));
     if (variant == 3) return p.k == 3 ? launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 3>(p, grid, s) : launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 0>(p, grid, s);
     const bool lean = conv_lean_ok(p);  // plain conv: the instantiation with the buffer-addressed prologue / epilogue
-    if (variant == 2 && split_wn1()) {  // the 128 x 64 tile with its four waves stacked along M (see conv_split16.h, PARROT_S16_WN1)
+    if constexpr (SCH::ID == SchF16x3::ID) if (variant == 2 && split_wn1()) {  // the 128 x 64 tile with its four waves stacked along M (see conv_split16.h, PARROT_S16_WN1; default scheme only: build time)
         if (p.k == 1 && p.nchunks % 4 == 0)
             return lean ? launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 1, 4, true>(p, grid, s) : launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 1, 4>(p, grid, s);
         switch (p.k) {

@@ -23,6 +23,7 @@ namespace parrot {
 #ifdef S16_TRACE
 // experiment builds only (tools/build_exp.sh s16trace -DS16_TRACE; tools/s16_trace.py): shader-clock marks of workgroup 0's waves --
 // [wave][0] start, [1] first slab staged, [2 + c] chunk c done, then epilogue done; [wave][62] / [63]: 100 MHz real-time clock
+// (trace builds compile every instantiation in tu_split16.hip, so that there is ONE copy of these)
 __device__ unsigned long long g_s16_trace[4 * 64];
 // ... and one record per workgroup of the launch: {start, end (100 MHz real-time clock), HW_ID, XCC_ID} (tools/s16_launch_timeline.py)
 constexpr int S16_WG_MAX = 16384;
@@ -361,22 +362,14 @@ inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
 // tile variants: 0 = 128 x 128 (waves 2x2, wave tile 64x64 = 4x4 MFMA tiles), 1 = 64 x 192 (waves 1x4, wave tile 64x48);
 //                2 = 128 x 64, 3 = 64 x 64: the same row tiling with a third / half of the columns, for launches that would not
 //                    give every CU a workgroup (small batches): the latency of a workgroup is its K loop x MFMAs per step
+//                    (8 x 1 / 4 x 1 waves, launch_conv_split16_small_s below);
+//                4 = 128 x 160 (waves 2x2, wave tile 64x80): for launches whose 128-column tiling ends in a half-empty round
+//                    (split16_wide_fits below)
 // PARROT_S16_M64 (default on; 0: off): the 64-row layers (stage 2, k = 11) on a 64 x 128 tile of 2 x 2 waves (32 x 64 each) at
 // three workgroups per CU instead of 64 x 192 (1 x 4 waves, 64 x 48 each) at two: 2.32 -> 2.21 ms per step
 inline bool split16_m64_small() {
     static const bool on = [] { const char* e = getenv("PARROT_S16_M64"); return !e || atoi(e) != 0; }();
     return on;
-}
-// PARROT_S16_N64 (experiment): 128-row layers on 128 x 64 tiles at three workgroups per CU
-inline bool split16_n64_three() {
-    static const bool on = [] { const char* e = getenv("PARROT_S16_N64"); return e && atoi(e) != 0; }();
-    return on;
-}
-//                4 = 128 x 160 (waves 2x2, wave tile 64x80): for launches whose 128-column tiling ends in a half-empty round
-//                    (split16_wide_fits below)
-inline int split16_wn1() {
-    static const int v = [] { const char* e = getenv("PARROT_S16_WN1"); return e ? atoi(e) : 2; }();
-    return v;
 }
 inline void split16_tile(int variant, int& bm, int& bn) {
     bm = (variant & 1) ? 64 : 128;
@@ -397,63 +390,45 @@ inline bool split16_wide_fits(long ncols, long rows, int n_mb, int n_cus) {
 }
 // (k = 3: three steps per 32-channel chunk do not amortise the larger slab -- measured 3-6 % slower than conv_split_kernel)
 inline bool split16_has(int scheme, int k) { return scheme == SchF16x3::ID && (k == 7 || k == 9 || k == 11); }
+// The small tiles (variants 2 / 3) run alone on their CU and stream their weights from L2 through the vector L1 at 64 B/clk: on a
+// 2 x 2 wave grid both column waves fetch the same row fragments -- 360 KB per 32-channel chunk at k = 11 = 5.6 k clocks against
+// 4.5 k of MFMA (tools/s16_trace.py).  Their waves are stacked along M instead (each wave all 64 columns): every weight fragment
+// is fetched once and more LDS fragments are read (128 B/clk).  One utterance, stage 0, k = 11: 32.8 -> 26.2 us per launch (8 x 1
+// waves; 30.2 with 4 x 1), FFN conv 35.0 -> 24.8, stage 2 (64 x 64 tile, 4 x 1 waves) 19.1 -> 11.2; B = 1 3.11 -> 2.90 ms, B = 4
+// 3.85 -> 3.62 ms (profiles/r03r_small_tile_wave_grid_ab.txt).
 template <class SCH>
-inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStream_t s) {
+inline hipError_t launch_conv_split16_small_s(int variant, const ConvParams& p, hipStream_t s) {
+    if (variant == 2) switch (p.k) {
+            case 7: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 7, 1>(p, s);
+            case 9: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 9, 1>(p, s);
+            case 11: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 11, 1>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    switch (p.k) {
+        case 7: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 7>(p, s);
+        case 9: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 9>(p, s);
+        case 11: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 11>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <class SCH>
+inline hipError_t launch_conv_split16_wide_s(int variant, const ConvParams& p, hipStream_t s) {  // variants 1 and 4
     if (variant == 4) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 7>(p, s);
             case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 9>(p, s);
             case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 11>(p, s);
             default: return hipErrorInvalidValue;
         }
-    if (variant == 2 && split16_n64_three()) switch (p.k) {
-            case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 7, 3>(p, s);
-            case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 11, 3>(p, s);
-            default: break;
-        }
-    // The small tiles run alone on their CU and stream their weights from L2 through the vector L1 at 64 B/clk: with the 2 x 2
-    // wave grid both column waves fetch the same row fragments -- 360 KB per 32-channel chunk at k = 11 = 5.6 k clocks against
-    // 4.5 k of MFMA (tools/s16_trace.py).  Waves stacked along M only (4 x 1, each wave all 64 columns) fetch every weight
-    // fragment once (2.8 k clocks) and read more LDS fragments instead (128 B/clk).  One utterance, stage 0, k = 11: 32.8 -> 26.2 us
-    // per launch (8 x 1 waves), FFN conv 35.0 -> 24.8, stage 2 (64 x 64 tile, 4 x 1) 19.1 -> 11.2; B = 1 3.11 -> 2.90 ms, B = 4
-    // 3.85 -> 3.62 ms.  PARROT_S16_WN1: 2 (default) eight waves on the 128-row tile / four on the 64-row one, 1 four waves on
-    // both, 0 the 2 x 2 / 1 x 4 grids.
-    if (variant == 2 && split16_wn1() == 2) switch (p.k) {
-            case 7: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 7, 1>(p, s);
-            case 9: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 9, 1>(p, s);
-            case 11: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 11, 1>(p, s);
-            default: return hipErrorInvalidValue;
-        }
-    if (variant == 2 && split16_wn1()) switch (p.k) {
-            case 7: return launch_conv_split16_t<SCH, 4, 1, 2, 4, 7>(p, s);
-            case 9: return launch_conv_split16_t<SCH, 4, 1, 2, 4, 9>(p, s);
-            case 11: return launch_conv_split16_t<SCH, 4, 1, 2, 4, 11>(p, s);
-            default: return hipErrorInvalidValue;
-        }
-    if (variant == 3 && split16_wn1()) switch (p.k) {
-            case 7: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 7>(p, s);
-            case 9: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 9>(p, s);
-            case 11: return launch_conv_split16_t<SCH, 4, 1, 1, 4, 11>(p, s);
-            default: return hipErrorInvalidValue;
-        }
-    if (variant == 2) switch (p.k) {
-            case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 7>(p, s);
-            case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 9>(p, s);
-            case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 2, 11>(p, s);
-            default: return hipErrorInvalidValue;
-        }
-    if (variant == 3) switch (p.k) {
-            case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 1, 7>(p, s);
-            case 9: return launch_conv_split16_t<SCH, 1, 4, 4, 1, 9>(p, s);
-            case 11: return launch_conv_split16_t<SCH, 1, 4, 4, 1, 11>(p, s);
-            default: return hipErrorInvalidValue;
-        }
-    if (variant == 1 && split16_m64_small() && p.k == 11) return launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3>(p, s);
-    if (variant == 1) switch (p.k) {
-            case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 7>(p, s);
-            case 9: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 9>(p, s);
-            case 11: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 11>(p, s);
-            default: return hipErrorInvalidValue;
-        }
+    if (split16_m64_small() && p.k == 11) return launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3>(p, s);
+    switch (p.k) {
+        case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 7>(p, s);
+        case 9: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 9>(p, s);
+        case 11: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 11>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <class SCH>
+inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStream_t s) {  // variant 0
     switch (p.k) {
         case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 7>(p, s);
         case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 9>(p, s);
@@ -461,9 +436,14 @@ inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStr
         default: return hipErrorInvalidValue;
     }
 }
+hipError_t launch_conv_split16_wide_f16x3(int variant, const ConvParams& p, hipStream_t s);   // csrc/tu_split16_wide.hip
+hipError_t launch_conv_split16_small_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16_small.hip
 hipError_t launch_conv_split16_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16.hip
 inline hipError_t launch_conv_split16(int scheme, int variant, const ConvParams& p, hipStream_t s) {
-    if (scheme == SchF16x3::ID) return launch_conv_split16_f16x3(variant, p, s);
+    if (scheme == SchF16x3::ID)
+        return (variant == 2 || variant == 3)   ? launch_conv_split16_small_f16x3(variant, p, s)
+               : (variant == 1 || variant == 4) ? launch_conv_split16_wide_f16x3(variant, p, s)
+                                                : launch_conv_split16_f16x3(variant, p, s);
     return hipErrorInvalidValue;
 }
 

@@ -7,6 +7,10 @@ hipError_t launch_conv_split16_f16x3(int variant, const ConvParams& p, hipStream
 hipError_t launch_resblock_split16_f16x3(int C, const ResblockSplitParams& p, hipStream_t s) { return launch_resblock_split16_s<SchF16x3>(C, p, s); }
 }  // namespace parrot
 #ifdef S16_TRACE
+namespace parrot {
+hipError_t launch_conv_split16_small_f16x3(int variant, const ConvParams& p, hipStream_t s) { return launch_conv_split16_small_s<SchF16x3>(variant, p, s); }
+hipError_t launch_conv_split16_wide_f16x3(int variant, const ConvParams& p, hipStream_t s) { return launch_conv_split16_wide_s<SchF16x3>(variant, p, s); }
+}  // namespace parrot
 extern "C" int parrot_debug_s16_trace(unsigned long long* out_host) {
     return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(parrot::g_s16_trace), sizeof(unsigned long long) * 4 * 64);
 }
