@@ -378,14 +378,16 @@ inline void split16_tile(int variant, int& bm, int& bn) {
 // Two 128-row workgroups fit a CU, so a launch runs in rounds of 2 x CUs workgroups, and a workgroup takes the same time whether
 // its CU is shared or not (tools/s16_launch_timeline.py): stage 0 at B = 64 is 1280 tiles of 128 x 128 = 2.5 rounds, the last one
 // with half of the slots empty.  The same layer on 128 x 160 tiles is 1024 workgroups = 2 full rounds of 1.25x the work each.
-// Rule: rounds x tile width, 160 only when it wins by more than 3 %.  (Tile shapes never change the arithmetic of an output.)
-// PARROT_S16_N160 (default on; 0: off)
+// Rule: rounds x tile width; ties go to the wider tile (a 64 x 80 wave tile fetches 20 % fewer weight fragments per MAC: stage 1 at
+// B = 64, 2560 -> 2048 workgroups = 5 -> 4 rounds, the conv_split16 kernels together 6.80 -> 6.74 ms per step).  (Tile shapes never
+// change the arithmetic of an output.)  PARROT_S16_N160: 2 (default) / 1 only when it wins by more than 3 % / 0 off
 inline bool split16_wide_fits(long ncols, long rows, int n_mb, int n_cus) {
-    static const bool on = [] { const char* e = getenv("PARROT_S16_N160"); return !e || atoi(e) != 0; }();
-    if (!on) return false;
+    static const int mode = [] { const char* e = getenv("PARROT_S16_N160"); return e ? atoi(e) : 2; }();
+    if (!mode) return false;
     const long slots = 2L * n_cus;
     const long wg128 = (ncols + 127) / 128 * rows * n_mb, wg160 = (ncols + 159) / 160 * rows * n_mb;
     const long cost128 = (wg128 + slots - 1) / slots * 128, cost160 = (wg160 + slots - 1) / slots * 160;
+    if (mode == 2) return cost160 <= cost128;
     return cost160 * 100 < cost128 * 97;
 }
 // (k = 3: three steps per 32-channel chunk do not amortise the larger slab -- measured 3-6 % slower than conv_split_kernel)
