@@ -29,7 +29,7 @@ def main():
         elif op.startswith("v_mfma"):
             seq.append("M")
         elif op.startswith("buffer_load"):
-            seq.append("L" if "dwordx4" in s else "l")
+            seq.append("D" if " lds" in s else ("L" if "dwordx4" in s else "l"))
         elif op.startswith("buffer_store"):
             seq.append("S")
         elif op.startswith("ds_read"):
