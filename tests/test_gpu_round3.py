@@ -182,3 +182,26 @@ def test_tie_guard_reevaluates_low_margin_positions_in_fp64(tmp_path):
     ids = r["ids"].cpu()
     assert bool((ids[mask] == 5).all()), "an exact tie goes to the FIRST maximal index (torch.argmax), here code 5"
     assert torch.equal(ids[mask], torch.argmax(ref["logits"], -1)[mask])
+
+
+@pytest.mark.gpu
+def test_tile_and_wave_grid_switches_do_not_change_a_bit():
+    """Tile shapes and wave grids partition the outputs among workgroups / waves; they never change the arithmetic of an output
+    (the batch-invariance of the path rests on it: DESIGN.md section 3).  Waveform hashes of dense-ish, ragged and tiny launches
+    under the non-default settings of every such switch equal the default's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def hashes(env):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "wav_hash.py"), "--quick"], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+
+    ref = hashes({})
+    assert len(ref.strip().splitlines()) == 3
+    for env in ({"PARROT_S16_N160": "0", "PARROT_SPLIT_WN1": "0", "PARROT_S16_M64": "0"}, {"PARROT_SMALL_TILES": "0", "PARROT_S16_N160": "1"},
+                {"PARROT_S16_PRIO": "1", "PARROT_MRF_STREAMS": "3"}):
+        assert hashes(env) == ref, env

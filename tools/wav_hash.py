@@ -17,7 +17,10 @@ def main():
     g = CodeGenerator(AttrDict(h))
     g.load_state_dict(synth.synth_voc_state_dict(h, seed=1234, scale=1.0))
     g = g.eval().to("cuda:0")
-    for B, U, ragged in [(64, 256, False), (64, 256, True), (32, 256, False), (16, 200, True), (8, 1500, True), (3, 77, True), (1, 256, False)]:
+    shapes = [(64, 256, False), (64, 256, True), (32, 256, False), (16, 200, True), (8, 1500, True), (3, 77, True), (1, 256, False)]
+    if "--quick" in sys.argv:
+        shapes = [(64, 256, True), (16, 200, True), (2, 77, True)]
+    for B, U, ragged in shapes:
         vb = synth.synth_voc_batch(B, U, h, seed=B + U)
         lens = None
         if ragged:
