@@ -544,6 +544,7 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         // small batches: a launch that would not give every CU a workgroup takes the 64-column tiles (2-3x the workgroups,
         // a half / third of the MFMAs per step: the per-launch latency is what counts there, not the operand reuse)
         if (small_tiles && (long)((p.Ncols + t.bn - 1) / t.bn) * B * ((c->M + t.bm - 1) / t.bm) < g_num_cus) variant16 += 2;
+        else if (small_tiles && p.Ncols <= 64) variant16 += 2;  // sequences of <= 64 steps (the TTE encoder side) would leave half of a 128-column tile empty
         else if (variant16 == 0 && split16_wide_fits(p.Ncols, B, (c->M + 127) / 128, g_num_cus)) variant16 = 4;  // 128 x 160: no half-empty last round
         split16_tile(variant16, t.bm, t.bn);
     } else if (c->prec >= 1) {
