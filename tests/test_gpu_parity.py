@@ -183,6 +183,33 @@ def test_conv1d_fuzz_wide_layers_all_kernel_variants():
         assert err <= 2e-5, (case, cin, cout, k, dil, B, T, pre, res, act, err)
 
 
+def test_conv1d_fuzz_chip_filling_launches_take_the_wide_tiles():
+    """The same check on launches of >= 256 workgroups, where conv_split16 picks between its 128 x 128, 128 x 160 and 64 x 128 tiles
+    by rounds x width (parrot_hip.hip / conv_split16.h split16_wide_fits): sequence lengths that leave partial 128- and 160-column
+    tiles, 64 / 128 / 256 rows, residual on and off -- against torch in fp64."""
+    rng = _rng(4242)
+    for case in range(10):
+        cin = int(rng.choice([64, 128, 256]))
+        cout = int(rng.choice([64, 128, 256]))
+        k = int(rng.choice([7, 11]))
+        dil = int(rng.choice([1, 3, 5]))
+        B = int(rng.choice([24, 33, 48]))
+        T = int(rng.choice([330, 641, 1250, 1285, 1601]))
+        pre, res = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        w = _randn(rng, cout, cin, k, scale=1.0 / np.sqrt(cin * k))
+        b = _randn(rng, cout, scale=0.1)
+        x = _randn(rng, B, cin, T)
+        r = _randn(rng, B, cout, T) if res else None
+        pad = dil * (k - 1) // 2
+        y_ref = F.conv1d((F.leaky_relu(x, 0.1) if pre else x).double(), w.double(), b.double(), padding=pad, dilation=dil)
+        if res:
+            y_ref = y_ref + r.double()
+        plan = ops.ConvPlan(w, b, dilation=dil, padding=pad, pre_act=int(pre), pre_slope=0.1, precision=ops.PREC_F16X3)
+        y = plan(x.to(DEV), None if r is None else r.to(DEV)).cpu().double()
+        err = float((y - y_ref).abs().max()) / max(1.0, float(y_ref.abs().max()))
+        assert err <= 2e-5, (case, cin, cout, k, dil, B, T, pre, res, err)
+
+
 def test_split_f16_scaling_covers_small_and_large_operands_and_overflows_loudly():
     """The fp16 split pre-scales activations by 2^3 and the layer's weights by a power of two: full relative accuracy for
     tiny weights (1e-6 scale) and activations from 1e-3 to 1e3 in one tensor; beyond fp16's range (|x| >= 8190) the
