@@ -40,11 +40,11 @@ SAMPLE_RATE = 16000             # reference utils/vocoder/config.json:32 (the me
 TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>", "conv_mfma_kernel<1,4,1,4,16,2>",
               "conv_mfma_kernel<2,2,2,2,32,3>", "conv_mfma_kernel<2,2,2,1,16,3>", "conv_mfma_kernel<1,4,1,2,16,4>",
               "conv_mfma16_kernel<8,2>", "conv_split_kernel<SCH,2,2,2,2,2>", "conv_split_kernel<SCH,1,4,2,2,2>", "resblock_fused16_kernel",
-              "conv_split_kernel<SCH,4,1,1,2,3>" if os.environ.get("PARROT_SPLIT_WN1", "1") != "0" else "conv_split_kernel<SCH,2,2,2,1,3>",  # the 128 x 64 tile
+              "conv_split_kernel<SCH,4,1,1,2,3>",  # the 128 x 64 tile (2 x 2 waves for the non-default schemes)
               "conv_split_kernel<SCH,1,4,1,4,2>", "resblock_split_kernel<SCH,2>", "resblock16_split_kernel<SCH>",
               "conv1_valu_kernel", "convt_valu_kernel<16,4,2,1>", "conv_split16_kernel<SCH,2,2,4,4>",
-              "conv_split16_kernel<SCH,2,2,2,4>" if os.environ.get("PARROT_S16_M64", "1") != "0" else "conv_split16_kernel<SCH,1,4,4,3>",  # the 64-row tile
-              "resblock_split16_kernel<SCH>", "conv_split16_kernel<SCH,2,2,4,5>",
+              "conv_split16_kernel<SCH,2,2,2,4>",  # the 64-row tile
+              "(unused)", "conv_split16_kernel<SCH,2,2,4,5>",
               "resblock_split_kernel<SCH,4>", "resblock_split_kernel<SCH,8>", "resblock_split_kernel<SCH,16>"]
 SCHEMES = {"f16x3": ("SchF16x3", 3), "bf16x6": ("SchBf16x6", 6), "bf16": ("SchBf16", 1), "f16": ("SchF16", 1), "f32": ("-", 1)}
 MFMA16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split scheme spends 3 (f16x3) or 6 (bf16x6) MFMA FMAs per algorithmic fp32 FMA

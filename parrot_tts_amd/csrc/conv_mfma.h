@@ -94,7 +94,6 @@ struct ConvParams {
                              // stream) folding makes every accumulation step round at ulp(|res|) instead of ulp(|sum|)
     int lean;                // conv_split_kernel: buffer-addressed prologue / epilogue for plain convs (conv_acc_init_lean)
     int n_cus;           // CUs of the device (workgroup slots per round = n_cus x workgroups per CU)
-    int prio;            // conv_split16: 0 no wave priorities; 1 progress-based (first quarter of the K loop 3 ... last quarter 0); 2 the same, last round of the launch only
     float acc_scale;         // split schemes with pre-scaled operands (conv_split.h): the accumulator holds acc_scale * sum
     float out_scale;         // = 1 / acc_scale (both exact powers of two; 1 for every other kernel)
 };

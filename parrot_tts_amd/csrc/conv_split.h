@@ -147,7 +147,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // both code paths in one kernel costs registers -- spills on the 2x2 wave tile).
 template <class SCH, int WAVES_M, int WAVES_N, int WM, int WN, int MINW, int K, int SUBS = 1, bool LEAN = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel(const ConvParams p) {
-    static_assert(SUBS == 1 || K == 1 || K == 3, "sub-slab staging: 1x1 convs (no halo) and k = 3 (two 16-channel slabs per barrier)");
+    static_assert(SUBS == 1 || K == 1, "sub-slab staging: 1x1 convs only (no halo)");
     constexpr int NPC = SCH::NP, NTERM = SCH::NT;
     constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
     constexpr int BM = WAVES_M * WM * 32;
@@ -301,24 +301,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
             constexpr int PAR = decltype(par)::value;
             const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
             const int cn2 = next_chunk(cn);
-#ifndef EXP_NO_SLABLOAD
             load_slab(cn);  // (after the last chunk: a harmless re-read, stored to the idle buffer)
-#endif
             load_b(Bv[PAR], xs, 0);
 #pragma unroll
             for (int j = 0; j < KS; ++j) {  // step j: sub-slab j / K, tap j % K
                 const int cur = (PAR + j) & 1;
                 const int tq = (j + 2 < KS) ? cc : (KS == 1 ? cn2 : cn);  // step + 2 in the flat order
                 const int tj = (j + 2 < KS) ? j + 2 : (KS == 1 ? 0 : j + 2 - KS);
-#ifdef EXP_A_CONST
-                const int soff = 0;
-                (void)tq; (void)tj;
-#else
                 const int soff = (tq * KS + tj) * STEP_BYTES;
-#endif
-#ifndef EXP_NO_B
                 if (j + 1 < KS) load_b(Bv[cur ^ 1], xs + ((j + 1) / K) * SUB_BYTES, (j + 1) % K);
-#endif
 #pragma unroll
                 for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
@@ -326,11 +317,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
 #pragma unroll
                         for (int nt = 0; nt < WN; ++nt)
                             acc[mt][nt] = mfma32<SCH>(A[cur][mt][SCH::pa(t)], Bv[cur][nt][SCH::pb(t)], acc[mt][nt]);
-#ifndef EXP_NO_A
 #pragma unroll
                     for (int pc = 0; pc < NPC; ++pc)
                         if (t == SCH::last_a(pc)) load_a_piece(A[cur], pc, soff);
-#endif
                 }
             }
             // Issue order of the block (hipcc would otherwise sink every prefetch down to its first use): one
@@ -366,12 +355,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split_kernel
                 for (int i = 0; i < WM; ++i) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // piece 0
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifndef EXP_NO_STORE   // (ablation builds, tools/build_exp.sh: timing only, results are wrong)
             store_slab((c + 1) & 1);
-#endif
-#ifndef EXP_NO_BARRIER
             __syncthreads();
-#endif
             cc = cn;
             cn = cn2;
         };
@@ -486,18 +471,9 @@ inline unsigned split_grid(const ConvParams& p, int bm) {  // 1-D: 8 XCDs x ceil
     const unsigned tiles = (unsigned)p.tiles_n * p.B, n_mb = (p.M + bm - 1) / bm;
     return (tiles + 7) / 8 * 8 * n_mb;
 }
-// PARROT_SPLIT_WN1 (default on; 0: the 2 x 2 wave grid): the 128 x 64 tile (1x1 convs, short sequences) with its four waves stacked
-// along M, each covering all 64 columns: every weight fragment is fetched by one wave instead of two (the vector L1 delivers
-// 64 B/clk, LDS 128 B/clk).  TTE 1x1 convs at B = 64: 0.77 -> 0.70 ms per step; one utterance: 0.55 -> 0.51 ms.
-inline bool split_wn1() {
-    static const bool on = [] { const char* e = getenv("PARROT_SPLIT_WN1"); return !e || atoi(e) != 0; }();
-    return on;
-}
-inline bool split_k3_subs2() {
-    // (measured +-0: the k = 3 layers of stages 0-1 move 2-3 TB/s of algorithmic bytes -- they are HBM-bound, not barrier-bound)
-    static const bool on = [] { const char* e = getenv("PARROT_K3_SUBS"); return e && atoi(e) != 0; }();
-    return on;
-}
+// The default scheme's 128 x 64 tile (1x1 convs, short sequences) has its four waves stacked along M, each covering all 64 columns:
+// every weight fragment is fetched by one wave instead of two (the vector L1 delivers 64 B/clk, LDS 128 B/clk).  TTE 1x1 convs at
+// B = 64: 0.77 -> 0.70 ms per step; one utterance: 0.55 -> 0.51 ms (round-3 A/B; the 2 x 2 grid stays for the other schemes).
 // the (tile, tap count) pairs of the synthesis path get the straight-line kernel, anything else the generic one
 template <class SCH>
 inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStream_t s) {
@@ -506,7 +482,7 @@ inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStrea
     dim3 grid(split_grid(p, bm));
     if (variant == 3) return p.k == 3 ? launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 3>(p, grid, s) : launch_conv_split_t<SCH, 1, 4, 1, 4, 2, 0>(p, grid, s);
     const bool lean = conv_lean_ok(p);  // plain conv: the instantiation with the buffer-addressed prologue / epilogue
-    if constexpr (SCH::ID == SchF16x3::ID) if (variant == 2 && split_wn1()) {  // the 128 x 64 tile with its four waves stacked along M (see conv_split16.h, PARROT_S16_WN1; default scheme only: build time)
+    if constexpr (SCH::ID == SchF16x3::ID) if (variant == 2) {  // the 128 x 64 tile with its four waves stacked along M (default scheme only: build time)
         if (p.k == 1 && p.nchunks % 4 == 0)
             return lean ? launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 1, 4, true>(p, grid, s) : launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 1, 4>(p, grid, s);
         switch (p.k) {
@@ -516,7 +492,7 @@ inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStrea
             default: return launch_conv_split_t<SCH, 4, 1, 1, 2, 3, 0>(p, grid, s);
         }
     }
-    if (variant == 2) {
+    if constexpr (SCH::ID != SchF16x3::ID) if (variant == 2) {
         if (p.k == 1 && p.nchunks % 4 == 0)  // 64 channels per barrier
             return lean ? launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4, true>(p, grid, s) : launch_conv_split_t<SCH, 2, 2, 2, 1, 3, 1, 4>(p, grid, s);
         switch (p.k) {  // (k > 1: sequences of <= 64 steps, i.e. the TTE encoder side)
@@ -535,7 +511,6 @@ inline hipError_t launch_conv_split_s(int variant, const ConvParams& p, hipStrea
         }
     switch (p.k) {
         case 3:
-            if (split_k3_subs2() && p.nchunks % 2 == 0 && SCH::NP <= 2) return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3, 2>(p, grid, s);  // 32 channels per barrier
             return lean ? launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3, 1, true>(p, grid, s) : launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 3>(p, grid, s);
         case 7: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 7>(p, grid, s);
         case 9: return launch_conv_split_t<SCH, 2, 2, 2, 2, 2, 9>(p, grid, s);

@@ -20,44 +20,6 @@
 
 namespace parrot {
 
-#ifdef S16_TRACE
-// experiment builds only (tools/build_exp.sh s16trace -DS16_TRACE; tools/s16_trace.py): shader-clock marks of workgroup 0's waves --
-// [wave][0] start, [1] first slab staged, [2 + c] chunk c done, then epilogue done; [wave][62] / [63]: 100 MHz real-time clock
-// (trace builds compile every instantiation in tu_split16.hip, so that there is ONE copy of these)
-__device__ unsigned long long g_s16_trace[4 * 64];
-// ... and one record per workgroup of the launch: {start, end (100 MHz real-time clock), HW_ID, XCC_ID} (tools/s16_launch_timeline.py)
-constexpr int S16_WG_MAX = 16384;
-__device__ unsigned long long g_s16_wg[S16_WG_MAX * 4];
-#define S16_WG_BEGIN()                                                                     \
-    do {                                                                                   \
-        if (tid == 0 && vb < S16_WG_MAX) {                                         \
-            unsigned hwid, xcc;                                                            \
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));             \
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));             \
-            g_s16_wg[vb * 4 + 0] = __builtin_amdgcn_s_memrealtime();               \
-            g_s16_wg[vb * 4 + 2] = hwid;                                           \
-            g_s16_wg[vb * 4 + 3] = xcc;                                            \
-        }                                                                                  \
-    } while (0)
-#define S16_WG_END()                                                                                             \
-    do {                                                                                                         \
-        if (tid == 0 && vb < S16_WG_MAX) g_s16_wg[vb * 4 + 1] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#define S16_MARK(i)                                                                                                 \
-    do {                                                                                                            \
-        if (vb == 0 && lane == 0 && (i) < 62) g_s16_trace[wave * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#define S16_REAL(i)                                                                                         \
-    do {                                                                                                    \
-        if (vb == 0 && lane == 0) g_s16_trace[wave * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define S16_MARK(i) do { } while (0)
-#define S16_REAL(i) do { } while (0)
-#define S16_WG_BEGIN() do { } while (0)
-#define S16_WG_END() do { } while (0)
-#endif
-
 template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kernel(const ConvParams p) {
     static_assert(K > 0, "tap count is a template parameter");
@@ -87,9 +49,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     const int mblock = seq % n_mb;
     const int tile_id = xcd * tpx + seq / n_mb;
     if (tile_id >= n_tiles || seq / n_mb >= tpx) return;
-    S16_REAL(62);
-    S16_MARK(0);
-    S16_WG_BEGIN();
     const int b = tile_id / p.tiles_n;
     const int tn0 = tile_id - b * p.tiles_n;
     const int t0 = tn0 * BN;
@@ -217,20 +176,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     load_slab(0);
     store_slab(0);
     __syncthreads();
-    S16_MARK(1);
 
-    // Wave priority by progress (p.prio): two workgroups share a CU and the SIMD arbiter serves the OLDER wave first, so of two
-    // workgroups started together one finishes after ~0.8 and the other after ~1.2 workgroup times (tools/s16_launch_timeline.py)
-    // and the launch ends with one workgroup per CU.  A wave that is further into its K loop yields to one that is behind.
-    const bool prio_on = p.prio == 1 || (p.prio == 2 && vb + 2 * p.n_cus >= (int)gridDim.x);
     for (int c = 0; c < nchunks; ++c) {  // one chunk = K straight-line steps
-        if (prio_on) {
-            const int q = c * 4 / nchunks;
-            if (q == 0) __builtin_amdgcn_s_setprio(3);
-            else if (q == 1) __builtin_amdgcn_s_setprio(2);
-            else if (q == 2) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
         const char* __restrict__ xs = smem_raw + (c & 1) * BUF_BYTES;
         const bool more = c + 1 < nchunks;
         if (more) load_slab(c + 1);
@@ -245,9 +192,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         acc[tm][tn] = mfma16<SCH>(A[tm][SCH::pa(t)], Bv[tn][SCH::pb(t)], acc[tm][tn]);
-#ifndef EXP_S16_NO_BRELOAD  // (timing ablation: the step's fragments are not re-read)
                         if (tm == TM - 1 && t == NTERM - 1 && j + 1 < K) load_b_tile(Bv[tn], xs, tn, j + 1);
-#endif
                     }
                 load_a_tile(A[tm], tm, c * K + j + 1);  // (past the last step: the stream is padded by one step)
             }
@@ -278,11 +223,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifndef EXP_S16_NO_STORE  // (timing ablation: no conversion, no LDS stores)
         if (more) store_slab((c + 1) & 1);
-#endif
         __syncthreads();
-        S16_MARK(2 + c);
     }
 
     // ---- epilogue (plain convs only): scale back, late residual / activation / MRF accumulation modes ------------------
@@ -339,9 +281,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
 #pragma unroll
             for (int r = 0; r < 4; ++r) row_tile_store(yt, v[tn][r], vo[tn], (m0 + r) * out_row_bytes);
     }
-    S16_MARK(2 + nchunks);
-    S16_REAL(63);
-    S16_WG_END();
 }
 
 template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
@@ -365,36 +304,31 @@ inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
 //                    (8 x 1 / 4 x 1 waves, launch_conv_split16_small_s below);
 //                4 = 128 x 160 (waves 2x2, wave tile 64x80): for launches whose 128-column tiling ends in a half-empty round
 //                    (split16_wide_fits below)
-// PARROT_S16_M64 (default on; 0: off): the 64-row layers (stage 2, k = 11) on a 64 x 128 tile of 2 x 2 waves (32 x 64 each) at
-// three workgroups per CU instead of 64 x 192 (1 x 4 waves, 64 x 48 each) at two: 2.32 -> 2.21 ms per step
-inline bool split16_m64_small() {
-    static const bool on = [] { const char* e = getenv("PARROT_S16_M64"); return !e || atoi(e) != 0; }();
-    return on;
-}
-inline void split16_tile(int variant, int& bm, int& bn) {
+// The 64-row layers with k = 11 (stage 2) run on a 64 x 128 tile of 2 x 2 waves (32 x 64 each) at three workgroups per CU instead of
+// 64 x 192 (1 x 4 waves, 64 x 48 each) at two: 2.32 -> 2.21 ms per step (round 3 A/B; the switch is gone, k = 7 / 9 keep 64 x 192).
+// (k: the layer's tap count -- the 64-row variant 1 is the 64 x 128 kernel for k = 11 and the 64 x 192 one for k = 7 / 9: the
+//  host's tile width must be the kernel's BN, or the launch carries workgroups whose tiles are all out of range)
+inline void split16_tile(int variant, int& bm, int& bn, int k = 11) {
     bm = (variant & 1) ? 64 : 128;
-    bn = variant == 4 ? 160 : variant >= 2 ? 64 : (variant ? (split16_m64_small() ? 128 : 192) : 128);
+    bn = variant == 4 ? 160 : variant >= 2 ? 64 : (variant ? (k == 11 ? 128 : 192) : 128);
 }
 // Two 128-row workgroups fit a CU, so a launch runs in rounds of 2 x CUs workgroups, and a workgroup takes the same time whether
-// its CU is shared or not (tools/s16_launch_timeline.py): stage 0 at B = 64 is 1280 tiles of 128 x 128 = 2.5 rounds, the last one
+// its CU is shared or not (profiles/r03q_s16_launch_timeline.jsonl): stage 0 at B = 64 is 1280 tiles of 128 x 128 = 2.5 rounds, the last one
 // with half of the slots empty.  The same layer on 128 x 160 tiles is 1024 workgroups = 2 full rounds of 1.25x the work each.
 // Rule: rounds x tile width; ties go to the wider tile (a 64 x 80 wave tile fetches 20 % fewer weight fragments per MAC: stage 1 at
 // B = 64, 2560 -> 2048 workgroups = 5 -> 4 rounds, the conv_split16 kernels together 6.80 -> 6.74 ms per step).  (Tile shapes never
-// change the arithmetic of an output.)  PARROT_S16_N160: 2 (default) / 1 only when it wins by more than 3 % / 0 off
+// change the arithmetic of an output.)
 inline bool split16_wide_fits(long ncols, long rows, int n_mb, int n_cus) {
-    static const int mode = [] { const char* e = getenv("PARROT_S16_N160"); return e ? atoi(e) : 2; }();
-    if (!mode) return false;
     const long slots = 2L * n_cus;
     const long wg128 = (ncols + 127) / 128 * rows * n_mb, wg160 = (ncols + 159) / 160 * rows * n_mb;
     const long cost128 = (wg128 + slots - 1) / slots * 128, cost160 = (wg160 + slots - 1) / slots * 160;
-    if (mode == 2) return cost160 <= cost128;
-    return cost160 * 100 < cost128 * 97;
+    return cost160 <= cost128;
 }
 // (k = 3: three steps per 32-channel chunk do not amortise the larger slab -- measured 3-6 % slower than conv_split_kernel)
 inline bool split16_has(int scheme, int k) { return scheme == SchF16x3::ID && (k == 7 || k == 9 || k == 11); }
 // The small tiles (variants 2 / 3) run alone on their CU and stream their weights from L2 through the vector L1 at 64 B/clk: on a
 // 2 x 2 wave grid both column waves fetch the same row fragments -- 360 KB per 32-channel chunk at k = 11 = 5.6 k clocks against
-// 4.5 k of MFMA (tools/s16_trace.py).  Their waves are stacked along M instead (each wave all 64 columns): every weight fragment
+// 4.5 k of MFMA (round-3 chunk trace, profiles/r03q_s16_chunk_trace.log).  Their waves are stacked along M instead (each wave all 64 columns): every weight fragment
 // is fetched once and more LDS fragments are read (128 B/clk).  One utterance, stage 0, k = 11: 32.8 -> 26.2 us per launch (8 x 1
 // waves; 30.2 with 4 x 1), FFN conv 35.0 -> 24.8, stage 2 (64 x 64 tile, 4 x 1 waves) 19.1 -> 11.2; B = 1 3.11 -> 2.90 ms, B = 4
 // 3.85 -> 3.62 ms (profiles/r03r_small_tile_wave_grid_ab.txt).
@@ -421,11 +355,10 @@ inline hipError_t launch_conv_split16_wide_s(int variant, const ConvParams& p, h
             case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 11>(p, s);
             default: return hipErrorInvalidValue;
         }
-    if (split16_m64_small() && p.k == 11) return launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3>(p, s);
+    if (p.k == 11) return launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3>(p, s);
     switch (p.k) {
         case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 7>(p, s);
         case 9: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 9>(p, s);
-        case 11: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 11>(p, s);
         default: return hipErrorInvalidValue;
     }
 }

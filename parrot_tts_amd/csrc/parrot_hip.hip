@@ -22,9 +22,6 @@
 #include "conv_valu.h"
 #include "kernels_misc.h"
 #include "resblock_split.h"
-#include "resblock_split16.h"
-#include "resblock_dual.h"
-#include "resblock_pdual.h"
 #include "resblock_fused.h"
 
 using namespace parrot;
@@ -513,14 +510,8 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.groups = c->groups; p.Mg = c->Mg;
     p.row_len = row_len; p.row_len_mul = row_len_mul; p.row_len_add = row_len_add;
     p.acc_scale = p.out_scale = 1.f;
-    {   // PARROT_LEAN_EPI (conv_split_kernel): 1 buffer-addressed prologue / epilogue for plain convs, 0 the generic one
-        static const int lean = [] { const char* e = getenv("PARROT_LEAN_EPI"); return e ? atoi(e) : 1; }();
-        p.lean = lean;
-    }
-    {   // PARROT_S16_PRIO (conv_split16_kernel): progress-based wave priorities, 0 off / 1 every workgroup / 2 last round only
-        static const int prio = [] { const char* e = getenv("PARROT_S16_PRIO"); return e ? atoi(e) : 0; }();
-        p.prio = prio; p.n_cus = g_num_cus;
-    }
+    p.lean = 1;  // conv_split_kernel: the buffer-addressed prologue / epilogue instantiations for plain convs (conv_lean_ok)
+    p.n_cus = g_num_cus;
     p.fold_res = c->late_res ? 0 : 1;
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
@@ -540,13 +531,15 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     static const bool small_tiles = [] { const char* e = getenv("PARROT_SMALL_TILES"); return !e || atoi(e) != 0; }();
     if (c->mfma16) {
         variant16 = c->M >= 128 ? 0 : 1;
-        split16_tile(variant16, t.bm, t.bn);
+        split16_tile(variant16, t.bm, t.bn, c->kk);
         // small batches: a launch that would not give every CU a workgroup takes the 64-column tiles (2-3x the workgroups,
         // a half / third of the MFMAs per step: the per-launch latency is what counts there, not the operand reuse)
         if (small_tiles && (long)((p.Ncols + t.bn - 1) / t.bn) * B * ((c->M + t.bm - 1) / t.bm) < g_num_cus) variant16 += 2;
         else if (small_tiles && p.Ncols <= 64) variant16 += 2;  // sequences of <= 64 steps (the TTE encoder side) would leave half of a 128-column tile empty
         else if (variant16 == 0 && split16_wide_fits(p.Ncols, B, (c->M + 127) / 128, g_num_cus)) variant16 = 4;  // 128 x 160: no half-empty last round
-        split16_tile(variant16, t.bm, t.bn);
+        split16_tile(variant16, t.bm, t.bn, c->kk);
+        // conv_split16_kernel addresses the (M, Tout) output / residual tile of a batch row with 32-bit byte offsets (RowTile)
+        if ((double)c->M * Tout * 4.0 >= 2147483648.0) return fail(PARROT_E_UNSUPPORTED, "conv_run: output row tile larger than 2 GiB");
     } else if (c->prec >= 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
         // better (76 vs 61 TF on the qkv projection); every other layer is faster on the 64x64 wave tile
@@ -624,7 +617,6 @@ struct parrot_voc {
     std::vector<std::unique_ptr<parrot_conv>> ups, rb;
     std::vector<uint16_t*> rb_stream;  // per (stage, kernel): concatenated split weight stream of the block (or null)
     std::vector<float> rb_wsc;         // per resblock conv: weight scale inside that stream (fp16 schemes; else 1)
-    std::vector<int> rb_kind;          // per (stage, kernel): 0 = resblock_split.h kernels, 1 = resblock_split16_kernel
     std::vector<size_t> rb_conv_halves;  // 16-bit words per conv in that stream
     int up_total = 1;
     bool odd_stage = false;            // some stage has odd kernel_size - rate: T_out = T u + 1 there (no constant hop)
@@ -749,12 +741,8 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     //   16 channels: packed here for the 16x16x32 MFMA (step = tap pair; lane = row l&15, channels 8(g&1).., tap 2*step + (g>>1)).
     v->rb_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
     v->rb_wsc.assign((size_t)w->n_rb, 1.f);
-    v->rb_kind.assign((size_t)cfg->n_stages * cfg->n_kernels, 0);
     v->rb_conv_halves.assign((size_t)cfg->n_stages * cfg->n_kernels, 0);
     const int NP = scheme_pieces(v->scheme);
-    // (resblock_split16_kernel: the pair kernel on 16x16x32 tiles -- half the LDS fragment bytes per MAC, but 208 VGPRs = two
-    //  workgroups per CU instead of three: 4.9 vs 4.7 ms per step, so it is opt-in)
-    static const bool rb16_on = [] { const char* e = getenv("PARROT_RB16"); return e && atoi(e) != 0; }();
     for (int i = 0; i < cfg->n_stages && v->scheme >= 1; ++i)
         for (int j = 0; j < cfg->n_kernels; ++j) {
             const int rk = cfg->resblock_kernel_sizes[j], C = v->chan(i);
@@ -763,35 +751,7 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
             const int steps = resblock_split_steps(C, rk);
             const size_t step_b = (size_t)NP * 1024, conv_b = (size_t)steps * step_b;
             v->rb_conv_halves[(size_t)i * cfg->n_kernels + j] = conv_b / 2;
-            if (C >= 32 && rb16_on && resblock_split16_has(v->scheme, C)) {
-                // 16x16x32 pair kernel: [conv][tap * (C/32) + chunk][row tile][piece][lane][8]; lane = row l & 15, channels 8 (l >> 4)..
-                const int CM = C / 16, NCH = C / 32, st16 = resblock_split16_steps(C, rk);
-                const size_t step_h = (size_t)CM * NP * 512, conv_h = (size_t)st16 * step_h;
-                std::vector<uint16_t> pk(((size_t)per_rb * st16 + 2) * step_h, 0);
-                for (int q = 0; q < per_rb; ++q) {
-                    const float* wq = w->rb_w[base + q];  // (C, C, rk)
-                    const float wsc = scheme_is_f16(v->scheme) ? f16_weight_scale(wq, (size_t)C * C * rk) : 1.f;
-                    v->rb_wsc[base + q] = wsc;
-                    for (int tap = 0; tap < rk; ++tap)
-                        for (int c32 = 0; c32 < NCH; ++c32)
-                            for (int tm = 0; tm < CM; ++tm) {
-                                uint16_t* g = pk.data() + (size_t)q * conv_h + ((size_t)tap * NCH + c32) * step_h + (size_t)tm * NP * 512;
-                                for (int lane = 0; lane < 64; ++lane)
-                                    for (int e = 0; e < 8; ++e) {
-                                        const int row = 16 * tm + (lane & 15), ch = 32 * c32 + 8 * (lane >> 4) + e;
-                                        uint16_t h[3];
-                                        split_weight(wq[((size_t)row * C + ch) * rk + tap], v->scheme, wsc, h);
-                                        for (int pc = 0; pc < NP; ++pc) g[pc * 512 + lane * 8 + e] = h[pc];
-                                    }
-                            }
-                }
-                uint16_t* st = nullptr;
-                HIP_TRY(hipMalloc((void**)&st, pk.size() * sizeof(uint16_t)));
-                HIP_TRY(hipMemcpy(st, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-                v->rb_stream[(size_t)i * cfg->n_kernels + j] = st;
-                v->rb_kind[(size_t)i * cfg->n_kernels + j] = 1;
-                v->rb_conv_halves[(size_t)i * cfg->n_kernels + j] = conv_h;
-            } else if (C >= 32) {  // the plans' streams are already [row tile][chunk * k + tap]
+            if (C >= 32) {  // the plans' streams are already [row tile][chunk * k + tap]
                 bool ok = true;
                 for (int q = 0; q < per_rb; ++q) {
                     const parrot_conv* pc = v->rb[base + q].get();
@@ -918,10 +878,7 @@ static int resblock_fused_launch(const parrot_voc* v, int stage, int j, const fl
 // Split-bf16 fused pair kernel for a 32-channel ResBlock1 block: the pairs are grouped into launches whose total reach
 // stays <= hmax columns per side (a 384-column window keeps >= 84 % of its columns at hmax = 30); every launch but
 // the last stores its running residual to a scratch buffer.
-static int rbs_hmax() {
-    static const int h = [] { const char* e = getenv("PARROT_RBS_HMAX"); return e ? atoi(e) : 30; }();
-    return h;
-}
+constexpr int RBS_HMAX = 30;
 static int resblock_split_launch(const parrot_voc* v, int stage, int j, const float* x, float* y, float* tmp_a, float* tmp_b, int B, int T,
                                  int epi, float div, hipStream_t s, const int32_t* row_len, int row_len_mul, int row_len_add,
                                  hipEvent_t before_last = nullptr) {
@@ -929,7 +886,7 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
     const int per_rb = 2 * c.n_dil, k = c.resblock_kernel_sizes[j], C = v->chan(stage);
     const int base = (stage * c.n_kernels + j) * per_rb;
     const int W = resblock_split_window(C), steps = resblock_split_steps(C, k);
-    const int hmax = rbs_hmax() * W / RBS_W;  // the same fraction of the window
+    const int hmax = RBS_HMAX * W / RBS_W;  // the same fraction of the window
     const uint16_t* stream = v->rb_stream[(size_t)stage * c.n_kernels + j];
     const float* src = x;
     int m0 = 0, n_launch = 0;
@@ -959,33 +916,13 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         p.epi = last ? epi : EPI_STORE;
         p.div = div; p.slope = 0.1f;
         p.row_len = row_len; p.row_len_mul = row_len_mul; p.row_len_add = row_len_add;
-        {
-            static const int stag = [] { const char* e = getenv("PARROT_STAGGER"); return e ? atoi(e) : 0; }();
-            static const int stag16 = [] { const char* e = getenv("PARROT_STAGGER16"); return e ? atoi(e) : -1; }();
-            p.stagger = (C == 16 && stag16 >= 0) ? stag16 : stag;
-#ifdef RBD_TRACE
-            {   // experiment builds: PARROT_RBD_TRACE_SEL = 100 * channels + taps selects the launches that record their phases
-                static const int sel = [] { const char* e = getenv("PARROT_RBD_TRACE_SEL"); return e ? atoi(e) : 0; }();
-                p.stagger = (sel == 100 * C + k) ? 1 : 0;
-            }
-#endif
-            p.first_round = g_num_cus * (scheme_pieces(v->scheme) == 3 ? 2 : 3);
-        }
         ProfRec rec{};
         const double macs = (double)B * C * C * k * T * (m1 - m0);
         if (last && before_last) HIP_TRY(hipStreamWaitEvent(s, before_last, 0));  // the MRF sum is accumulated in branch order
-        const bool k16 = v->rb_kind[(size_t)stage * c.n_kernels + j] == 1;
         // rows: one per kernel instantiation (C = 32 / 64 / 128 / 256 are resblock_split_kernel<SCH, 2 / 4 / 8 / 16>)
-        const int prow = C == 16 ? 6 : k16 ? 11 : C == 32 ? 5 : C == 64 ? 13 : C == 128 ? 14 : 15;
+        const int prow = C == 16 ? 6 : C == 32 ? 5 : C == 64 ? 13 : C == 128 ? 14 : 15;
         if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + prow, 2.0 * macs, 4.0 * B * (double)C * T * (2 + (p.epi != EPI_STORE ? 1 : 0)), s));
-        // PARROT_RB_DUAL (experiments, resblock_dual.h; measured slower): 0 (default) the kernels of
-        // resblock_split.h, 1 the lean-VALU variant with one window per workgroup, 2 dual-window anti-phase workgroups
-        static const int dual_mode = [] { const char* e = getenv("PARROT_RB_DUAL"); return e ? atoi(e) : 0; }();
-        // 3: the persistent dual-window kernel (resblock_pdual.h; 32 / 64 channels)
-        HIP_TRY(k16 ? launch_resblock_split16(v->scheme, C, p, s)
-                    : (dual_mode == 3 && resblock_pdual_has(v->scheme, C)) ? launch_resblock_pdual_f16x3(C, p, g_num_cus, s)
-                    : (dual_mode > 0 && dual_mode < 3 && resblock_dual_has(v->scheme, C)) ? launch_resblock_dual_f16x3(C, dual_mode == 2 ? 2 : 1, p, s)
-                                                                          : launch_resblock_split(v->scheme, C, p, s));
+        HIP_TRY(launch_resblock_split(v->scheme, C, p, s));
         if (g_prof_on) TRY(prof_close(rec, s));
         src = p.y;
         m0 = m1;
@@ -1040,7 +977,7 @@ extern "C" int parrot_voc_receptive_units(const parrot_voc_t* v) { return v ? vo
 
 static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_stride, const int64_t* spkr, const float* feats,
                             int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
-                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream);
+                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream, int ns_sized = 0);
 
 extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
                                   int32_t U, float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
@@ -1085,6 +1022,7 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
     int32_t* lens = a.take<int32_t>((size_t)B);
     a.off = align_up(a.off, 256);
     const size_t inner = parrot_voc_workspace_bytes(v, B, span);
+    const int ns_span = voc_streams(v, B, span);  // (what parrot_voc_workspace_bytes(v, B, span) reserved branch temporaries for)
     if (!a.ok || a.off + inner > ws_bytes) return fail(PARROT_E_NOMEM, "voc_forward_chunked: workspace too small");
     void* inner_ws = (char*)ws + a.off;
     for (int start = 0; start < U; start += chunk_units) {
@@ -1094,7 +1032,9 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
             hipLaunchKernelGGL(rebase_lens_kernel, dim3((B + 255) / 256), dim3(256), 0, s, unit_lens, lens, B, lo, n);
             HIP_TRY(hipGetLastError());
         }
-        TRY(voc_forward_impl(v, code + lo, U, spkr, nullptr, 0, unit_lens ? lens : nullptr, B, n, tmp, nullptr, inner_ws, inner, stream));
+        // (every chunk runs with the branch-stream count the workspace was sized for: a trailing chunk with B x n <= 8192 < B x span
+        //  would otherwise ask for 3 + 3 x 3 activation buffers where 3 + 3 were reserved)
+        TRY(voc_forward_impl(v, code + lo, U, spkr, nullptr, 0, unit_lens ? lens : nullptr, B, n, tmp, nullptr, inner_ws, inner, stream, ns_span));
         HIP_TRY(hipMemcpy2DAsync(wav_out + (size_t)start * hop, (size_t)U * hop * sizeof(float), tmp + (size_t)(start - lo) * hop,
                                  (size_t)n * hop * sizeof(float), (size_t)(stop - start) * hop * sizeof(float), B, hipMemcpyDeviceToDevice, s));
     }
@@ -1103,7 +1043,7 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
 
 static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_stride, const int64_t* spkr, const float* feats,
                             int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
-                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
+                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream, int ns_sized) {
     if (!v || !code || !wav_out || !ws) return fail(PARROT_E_INVALID, "voc_forward: null argument");
     {
         const int base = v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1);
@@ -1117,7 +1057,8 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
     Arena a(ws, ws_bytes);
     float* x0 = a.take<float>((size_t)B * c.model_in_dim * U);
     const size_t mx = voc_max_act(v, B, U);
-    const int ns = voc_streams(v, B, U);
+    // concurrent MRF branches: the shape's own rule, or -- chunked path -- the count the caller sized the workspace with
+    const int ns = ns_sized > 0 ? std::min(ns_sized, v->mrf_streams) : voc_streams(v, B, U);
     const int ns_alloc = ns;  // (parrot_voc_workspace_bytes reserves exactly these)
     std::unique_lock<std::mutex> side_lock(v->side_mu, std::defer_lock);
     if (ns > 1) side_lock.lock();
@@ -1437,24 +1378,19 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
         TRY(conv_launch(L->in_proj.get(), w.qkv1, nullptr, w.qkv2, B, T, EPI_STORE, 1.f, 0, 0, 0, s));
     }
     const long DT = (long)D * T;
-    static const bool fuse_attn = [] { const char* e = getenv("PARROT_FUSED_ATTN"); return !e || atoi(e) != 0; }();
     if (t->flash) {  // any T, online softmax, no score tensor (attn.h: attn_flash_kernel)
         AttnParams p{};
         p.qkv = w.qkv2; p.valid = valid; p.ctx = w.ctx;
         p.T = T; p.H = H; p.D = D; p.hd = hd;
         p.alpha = (float)std::sqrt(1.0 / (double)hd);
         HIP_TRY(launch_attn_flash(p, B, s));
-    } else if (fuse_attn && T <= ATTN_TMAX && hd == 128) {  // scores, softmax and context in one launch (attn.h)
+    } else if (T <= ATTN_TMAX && hd == 128) {  // scores, softmax and context in one launch (attn.h)
         AttnParams p{};
         p.qkv = w.qkv2; p.valid = valid; p.ctx = w.ctx;
         p.T = T; p.H = H; p.D = D; p.hd = hd;
         p.alpha = (float)std::sqrt(1.0 / (double)hd);
-        static const int qt = [] { const char* e = getenv("PARROT_ATTN_QT"); return (e && atoi(e) == 64) ? 64 : 32; }();
-        const size_t lds = (size_t)qt * (((T + 31) / 32) * 32 + 1) * sizeof(float);
-        static DynLdsOnce lds_once;
-        HIP_TRY(ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(attn_fused_kernel<128, 64>), (size_t)((size_t)64 * (ATTN_TMAX + 1) * sizeof(float))));
-        if (qt == 64) hipLaunchKernelGGL((attn_fused_kernel<128, 64>), dim3((T + 63) / 64, B * H), dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((attn_fused_kernel<128, 32>), dim3((T + 31) / 32, B * H), dim3(256), lds, s, p);
+        const size_t lds = (size_t)32 * (((T + 31) / 32) * 32 + 1) * sizeof(float);  // 32-query tiles (33 KiB at T = 256: no opt-in needed)
+        hipLaunchKernelGGL((attn_fused_kernel<128, 32>), dim3((T + 31) / 32, B * H), dim3(256), lds, s, p);
         HIP_TRY(hipGetLastError());
     } else {
     {   // scores[b,h][tq][tk] = sum_c (q[c][tq] * sqrt(1/hd)) * k[c][tk]

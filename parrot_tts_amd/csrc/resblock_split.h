@@ -51,22 +51,7 @@ struct ResblockSplitParams {
     const int32_t* row_len;
     int row_len_mul;
     int row_len_add;         // true length of a row of n > 0 units at this layer = n * row_len_mul + row_len_add (odd k - u upsampling stages add samples)
-    int stagger;              // phase stagger of co-resident workgroups, in units of 64 clocks per wave slot (0 = off)
-    int first_round;          // workgroups of the launch's first round (CUs x workgroups per CU): only they are delayed
 };
-
-// Co-resident workgroups of these kernels start together, take the same time and therefore stay in LOCKSTEP: all of them
-// convert (VALU busy, matrix pipe idle) and then all of them multiply (matrix pipe busy, VALU idle).  Delaying the first
-// round's workgroups by their hardware wave slot (HW_ID.WAVE_ID: the co-resident waves of a SIMD have different slots)
-// shifts the phases once; every later workgroup inherits the phase of the one it replaces.
-__device__ __forceinline__ void phase_stagger(int units, int first_round) {
-    if (units > 0 && (int)blockIdx.x < first_round) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        const int slot = hwid & 15;
-        for (int i = 0; i < slot * units; i += 64) __builtin_amdgcn_s_sleep(64);
-    }
-}
 
 constexpr int RBS_W = 384;  // 32-channel window (the 64-channel kernel uses half: the same 72 KiB of LDS)
 
@@ -97,7 +82,6 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
     const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
     const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);  // window not fully inside the row
-    phase_stagger(p.stagger, p.first_round);
 
     int col[NTW];   // this lane's window column per tile
     bool tok[NTW];  // ... inside the sequence
@@ -213,10 +197,8 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int set = ch & 1;
-#ifndef EXP_RB_NO_B
                 if (ch + 1 < NCH) load_b(Bv[set ^ 1], ch + 1, shift);
                 else load_b(Bv[set ^ 1], 0, shift + dil);
-#endif
                 const int nx = (ch + 2 < NCH) ? gbase + (ch + 2) * K + j : n0 + (ch + 2 - NCH) * K;  // two steps ahead
 #pragma unroll
                 for (int t = 0; t < NTERM; ++t) {
@@ -265,9 +247,7 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
             for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? bv[r] * s1 : bv[r];
         conv(p.dil[m]);
         __syncthreads();  // every wave is done reading P
-#ifndef EXP_RB_NO_WRITE
         write_p(acc, 1.f / p.wsc[m]);  // P = split(lrelu(h)), masked: acc / s1 * XS
-#endif
         __syncthreads();
         // R = conv_1(P) + b2 + R
         bias_rows(p.bias[m + 1], bv);
@@ -354,7 +334,6 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
     const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);
     const int col0 = wave * (NT * 16) + l15;  // this lane's window column in tile 0 (tile nt adds 16 nt)
-    phase_stagger(p.stagger, p.first_round);
 
     f32x4 R[NT], acc[NT];
     {
@@ -446,10 +425,8 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
 #pragma unroll
                 for (int pr = 0; pr < NP; ++pr) {
                     const int cur = pr & 1;  // NP is even: every step starts on operand set 0
-#ifndef EXP_RB_NO_B
                     if (pr + 1 < NP) load_b(Bv[cur ^ 1], pr + 1, tpd + 2 * s * dil);
                     else load_b(Bv[cur ^ 1], 0, tpd + 2 * (s + 1) * dil);  // (after the last step: discarded)
-#endif
 #pragma unroll
                     for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
@@ -493,9 +470,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
             for (int r = 0; r < 4; ++r) acc[nt][r] = bv[r];
         conv(p.dil[m]);
         __syncthreads();
-#ifndef EXP_RB_NO_WRITE
         write_p(acc, 1.f / p.wsc[m]);
-#endif
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + 1][4 * g4 + r];
@@ -571,13 +546,8 @@ inline hipError_t launch_resblock_split(int scheme, int C, const ResblockSplitPa
 // odd tap counts with (k + 1) / 2 even; at 64 channels the 192-column window loses too much to the halo of k = 11
 // at 128 channels (window 96) only the k = 3 pairs: the layer kernel is latency-bound there (three MFMA steps per chunk), the
 // fused pair reads x once and writes y once instead of five passes, and a pair's reach (<= 6) leaves >= 87 % of the window
-inline bool resblock_split_wide_k3() {
-    static const bool on = [] { const char* e = getenv("PARROT_RBS_WIDE"); return !e || atoi(e) != 0; }();
-    return on;
-}
 inline bool resblock_split_has(int C, int k) {
-    if (C == 256) return k == 3 && resblock_split_wide_k3();
-    if (C == 128) return k == 3 && resblock_split_wide_k3();
+    if (C == 256 || C == 128) return k == 3;
     if (C == 64) return k == 3 || k == 7;
     return (C == 32 || C == 16) && (k == 3 || k == 7 || k == 11);
 }

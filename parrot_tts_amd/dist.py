@@ -145,10 +145,13 @@ def _collect(send: torch.Tensor, out, dst: int, key) -> None:
             ok = 0
         if _gather_mode == "gather":
             return
-        # all ranks must agree on the fallback (a failure on the root only would otherwise deadlock the next call)
+        # all ranks must agree on the fallback (a failure on the root only would otherwise deadlock the next call).  The
+        # agreement is reached ONCE: after the first call every rank latches the mode, so later steps carry no host-side
+        # all_reduce (a cross-rank host barrier per step would stop the host from running ahead of the device)
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_meta_pg())
         if int(flag) == 1:
+            _gather_mode = "gather"
             return
         _gather_mode = "allgather"
         if rank == 0:

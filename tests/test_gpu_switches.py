@@ -1,5 +1,7 @@
 """GPU: the library's runtime switches are read once per process, so each alternative code path is
-exercised in its own subprocess on a slice of the parity suite: full-size vocoder + TTE goldens and the ragged-row test."""
+exercised in its own subprocess on a slice of the parity suite: full-size vocoder + TTE goldens and the ragged-row test.
+Every switch the library still reads (PARROT_PRECISION, _FUSED, _MRF_STREAMS, _SMALL_TILES, _MFMA16, _FLASH_ATTN, _TTE_MERGE,
+_VALU_KERNELS, _TIE_GUARD) appears below with its non-default value (the precision modes also run in-process in the parity tests)."""
 import os
 import subprocess
 import sys
@@ -13,9 +15,11 @@ SLICE = "voc_full_u40 or voc_small_resblock2 or tte_full_forced or ragged_batch_
 
 SWITCHES = [
     {"PARROT_MRF_STREAMS": "1"},                       # MRF branches on one stream (the small-batch default is three)
-    {"PARROT_MRF_STREAMS": "3", "PARROT_RB16": "1"},   # forced branch streams + the 16x16x32 fused pair kernel
+    {"PARROT_MRF_STREAMS": "3", "PARROT_SMALL_TILES": "0"},  # forced branch streams, no small tiles for under-filled launches
     {"PARROT_MFMA16": "0", "PARROT_FLASH_ATTN": "0"},  # 32x32x16 layer kernel everywhere, fp32-MFMA attention cores
-    {"PARROT_TTE_MERGE": "0", "PARROT_VALU_KERNELS": "0", "PARROT_STAGGER": "32"},
+    {"PARROT_TTE_MERGE": "0", "PARROT_VALU_KERNELS": "0"},
+    {"PARROT_FUSED": "0", "PARROT_TIE_GUARD": "0"},    # every ResBlock layer by layer, tie guard off
+    {"PARROT_FUSED": "1", "PARROT_PRECISION": "f32"},  # exact fp32 MFMA incl. the fused 32-channel whole-block kernel
 ]
 
 

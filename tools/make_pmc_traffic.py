@@ -24,7 +24,6 @@ def norm(name: str) -> str:
         return m.group(1) + ">"
     if name == "conv1_valu7_vec_kernel":
         return "conv1_valu_kernel"
-    name = re.sub(r"^(resblock_split16_kernel)<(Sch\w+),\d+>$", r"\1<\2>", name)
     return re.sub(r"^(conv1_valu_kernel)<\d+>$", r"\1", name)  # instantiations that share one bench.py row
 
 
