@@ -402,7 +402,9 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "units_per_utt": 4 * S, "sample_rate": SAMPLE_RATE,
                        "parallelism": f"dp{world} (batch shard, RCCL waveform gather)",
                        "weights": "seeded synthetic, reference checkpoint layouts (TTE seed 42 forced duration 4; vocoder seed 1234)",
-                       "note": "reference vocoder is 16 kHz / 320 samples per unit (utils/vocoder/config.json:24,32), not 22.05 kHz"},
+                       "note": "reference vocoder is 16 kHz / 320 samples per unit (utils/vocoder/config.json:24,32), not 22.05 kHz; "
+                               "BASELINE configs[2] says single-speaker: this run uses the 10-speaker TTE (speaker_emb present, one extra "
+                               "add kernel per step, parrot.py:98-99) and the multispkr vocoder -- a superset of the single-speaker work"},
             "err_vs_fp64": product_error_vs_fp64(),
             "roofline": roof,
             # the waveform gather's share of a step (max over ranks, CUDA events around the collective; 0 at N = 1) and what the

@@ -72,6 +72,53 @@ def test_two_rank_shard_and_gather(tmp_path):
     assert (tmp_path / "ok").read_text() == "ok"
 
 
+def _worker8(rank, world, port, out_dir, n_rows):
+    """BASELINE configs[3] in shape: 512 utterances (or 509: B % world != 0) sharded over 8 ranks, ragged lengths per row and a
+    data-dependent padded length per shard, gathered to rank 0 in rank order -- twice (receive-buffer reuse, latched gather mode)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from parrot_tts_amd import dist as pdist
+    r, w, _ = pdist.init_from_env("gloo")
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(3, 41, (n_rows,), generator=g)                      # samples per row (same on every rank)
+    full = {"phones": torch.arange(n_rows)[:, None].repeat(1, 4), "speaker": torch.arange(n_rows) % 10, "meta": "kept as is"}
+    mine = pdist.shard_batch(full, r, w)
+    sl = pdist.shard_rows(n_rows, r, w)
+    assert mine["meta"] == "kept as is" and torch.equal(mine["phones"], full["phones"][sl])
+    assert sl.stop - sl.start in (n_rows // w, n_rows // w + 1)
+    for rep in range(2):
+        my_lens = lens[sl]
+        n_r = int(my_lens.max())                                              # this shard's padded length (L = max over ITS rows)
+        wav = torch.zeros((sl.stop - sl.start, 1, n_r))
+        for i, row in enumerate(range(sl.start, sl.stop)):
+            wav[i, 0, : int(lens[row])] = row * 1000.0 + rep + torch.arange(float(lens[row]))
+        got = pdist.gather_waveforms(wav, dst=0, n_samples=my_lens)
+        if r == 0:
+            gw, gl = got
+            assert gw.shape == (n_rows, 1, max(int(lens[pdist.shard_rows(n_rows, q, w)].max()) for q in range(w)))
+            assert torch.equal(gl, lens)
+            for row in range(n_rows):
+                n = int(lens[row])
+                assert torch.equal(gw[row, 0, :n], row * 1000.0 + rep + torch.arange(float(n))), row
+                assert float(gw[row, 0, n:].abs().sum()) == 0.0
+        else:
+            assert got is None
+    assert pdist.dist_info()["nranks"] == 8 and pdist.dist_info()["gather"] in ("gather", "allgather")  # latched after the first call
+    if r == 0:
+        open(os.path.join(out_dir, f"ok{n_rows}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_shard_and_gather_of_512_and_509_rows(tmp_path):
+    """the N = 8 layout of BASELINE configs[3] (512 -> 8 x 64 rows) rehearsed without hardware, plus a row
+    count that does not divide (509 -> 64 x 5 + 63 x 3)."""
+    for n_rows in (512, 509):
+        mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path), n_rows), nprocs=8, join=True)
+        assert (tmp_path / f"ok{n_rows}").read_text() == "ok"
+
+
 def test_single_process_is_a_no_op():
     sys.path.insert(0, ROOT)
     from parrot_tts_amd import dist as pdist

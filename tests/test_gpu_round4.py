@@ -48,3 +48,30 @@ def test_chunked_workspace_covers_a_trailing_chunk_below_the_branch_stream_thres
     for r in (0, 17, 39):
         n = int(lens[r]) * hop
         assert float((a[r, :, :n] - c[r, :, :n]).abs().max()) <= 2e-5
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_rehearses_eight_ranks_on_one_gpu():
+    """bench.py exactly as the driver launches it for N = 8 (torch.distributed.run, one process per rank), all
+    eight ranks on the one visible GPU with gloo carrying the collective: rc 0, ONE JSON line from rank 0 whose `dist` says 8
+    ranks, whose global batch is 8 x the per-GPU batch, and whose gather took measurable time."""
+    env = dict(os.environ, PARROT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--no-cpu-baseline", "--no-alt"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["dist"]["nranks"] == 8 and res["dist"]["backend"] == "gloo"
+    assert res["config"]["global_batch"] == 16 and res["config"]["per_gpu_batch"] == 2
+    assert abs(res["value"] * res["ms_per_step"] / 1e3 - 16 * 256 * 320) < 1.0
+    assert 0.0 < res["gather_ms"] < res["ms_per_step"]
+    assert "10-speaker" in res["config"]["note"]
