@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PARROT_ABI_VERSION 3
+#define PARROT_ABI_VERSION 4
 
 enum {
     PARROT_OK = 0,
@@ -89,6 +89,10 @@ int parrot_set_default_precision(int32_t prec);
 /* Fused ResBlock kernels (csrc/resblock_split.h, resblock_fused.h): 0 off (layer by layer), 1 every eligible stage,
  * 2 (default; env PARROT_FUSED) all but the exact-fp32 32-channel kernel.  Default for handles created afterwards. */
 int parrot_set_fused_resblocks(int32_t mode);
+/* FFT blocks project twice on each side of the attention core (quirk Q3, modules/fft.py:48-57: qkv then MHA in_proj; MHA
+ * out_proj then wo; all bias-free).  1 (default; env PARROT_TTE_MERGE): each pair is evaluated as its fp64-formed product, one
+ * launch; 0: one after the other as the reference does.  Default for handles created afterwards. */
+int parrot_set_tte_merge(int32_t on);
 
 int parrot_conv_create(parrot_conv_t** out, const parrot_conv_desc* d, const float* w_host, const float* bias_host);
 void parrot_conv_destroy(parrot_conv_t*);
@@ -151,7 +155,20 @@ typedef struct {
 } parrot_voc_weights;
 
 int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w);
+/* The same with this handle's own precision (PARROT_PREC_*, -1 = the process default) and fused-ResBlock mode (0 / 1 / 2,
+ * -1 = default): what the shims' range-safe fallback uses to rebuild a handle in PARROT_PREC_BF16X6 (fp32's range) after the
+ * default fp16x3 scheme reported PARROT_E_NONFINITE -- reference checkpoints carry no range promise (utils/vocoder/models.py has
+ * no normalisation layer), so |activation| < 8190 cannot be assumed of a real one. */
+int parrot_voc_create_ex(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w, int32_t precision,
+                         int32_t fused_resblocks);
 void parrot_voc_destroy(parrot_voc_t*);
+/* PARROT_PREC_* this handle was created with (the "precision in use" after a fallback). */
+int parrot_voc_precision(const parrot_voc_t*);
+/* Debug aid: headroom to the fp16 split scheme's range.  While dst_dev != NULL every conv launched by parrot_voc_forward records
+ * max |input element| into dst_dev[group] (device floats, atomic max; the caller zeroes them): group 0 = conv_pre, 1 + i = the
+ * layers of stage i (ups_i, its ResBlock convs), n_stages + 1 = conv_post.  Fused ResBlock launches only see their block's input:
+ * create the handle with fused_resblocks = 0 to cover every layer.  NULL switches it off. */
+int parrot_voc_debug_absmax(parrot_voc_t*, float* dst_dev);
 size_t parrot_voc_workspace_bytes(const parrot_voc_t*, int32_t B, int32_t U);
 /* code (B,U) int64, spkr (B,1) int64 or NULL -> wav (B,1,U*prod(rates)) fp32 in (-1,1).
  * unit_lens: optional (B) int32 device array of real units per row (ragged batch padded to U): every layer applies its
@@ -182,6 +199,9 @@ int parrot_voc_check(parrot_voc_t*, void* stream);
 /* The same flag WITHOUT a synchronisation: copies its value (0 = ok, 1 / 2 bad unit / speaker id, 5 non-finite sample) to
  * dst_dev[0] (device memory) on `stream` and clears it -- for callers that fetch it with a device-to-host copy they do anyway. */
 int parrot_voc_status_async(parrot_voc_t*, int32_t* dst_dev, void* stream);
+/* ... and without clearing it: the shims look at it once, synchronously, after the FIRST forward of every handle (range-safe
+ * fallback: 5 -> rebuild in PARROT_PREC_BF16X6 and re-run); any other value stays set for the regular reporting path. */
+int parrot_voc_status_peek_async(parrot_voc_t*, int32_t* dst_dev, void* stream);
 /* Receptive field of the generator in units, either side of an output frame, from the handle's configuration (interval
  * propagation through conv_post, the MRF stages, the transposed convs of reference utils/vocoder/models.py:80-83 and conv_pre):
  * 21 for the shipped config.  The default halo of parrot_voc_forward_chunked. */
@@ -226,7 +246,12 @@ typedef struct {
 } parrot_tte_weights;
 
 int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w);
+/* The same with this handle's own precision (PARROT_PREC_*, -1 = default) and projection merge (0 / 1, -1 = default): the
+ * range-safe fallback of the shims, and the merged-vs-unmerged rows of the parity report. */
+int parrot_tte_create_ex(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w, int32_t precision,
+                         int32_t merge_projections);
 void parrot_tte_destroy(parrot_tte_t*);
+int parrot_tte_precision(const parrot_tte_t*);
 /* `state` carries the encoder output + duration prefix sums from encode to decode (sized by B,S);
  * `ws` is scratch: encode needs workspace_bytes(B,S,0), decode workspace_bytes(B,S,L).         */
 size_t parrot_tte_state_bytes(const parrot_tte_t*, int32_t B, int32_t S);
@@ -254,8 +279,14 @@ int parrot_tte_check(parrot_tte_t*, void* stream);
  * fp32 logits move by ~1.2e-5 with the CPU thread count (tests/test_oracle_golden.py), so an id with a smaller margin is not
  * determined by the reference itself. */
 int parrot_tte_guard_stats_async(parrot_tte_t*, int32_t* dst_dev, void* stream);
+/* The guard's re-evaluation starts one layer before the head when the last decoder block's conv2 is 1x1 (the shipped config): that
+ * conv2 + bias + residual (modules/fft.py:81,99) are recomputed in fp64 from the block's own fp32 intermediates, then the head.
+ * logits_dev (max_n x n_codes floats) / list_dev (2 max_n ints: (b, t) pairs) <- the refined logits of the guarded positions of
+ * the last decode (first guard_stats[0], at most 256); device memory, no synchronisation.  Tests / parity reports. */
+int parrot_tte_guard_logits(parrot_tte_t*, float* logits_dev, int32_t* list_dev, int32_t max_n, void* stream);
 /* The same flag without a synchronisation (3 / 4 bad phone / speaker id, 5 non-finite logits): see parrot_voc_status_async. */
 int parrot_tte_status_async(parrot_tte_t*, int32_t* dst_dev, void* stream);
+int parrot_tte_status_peek_async(parrot_tte_t*, int32_t* dst_dev, void* stream);
 /* Tests / error localisation: while set, the next encode / decode calls copy the channel-first (B, D, T) activation
  * after each stage to the given DEVICE buffers (NULL entries are skipped): enc_ptrs[0] = embedding + pe[S],
  * enc_ptrs[1 + n] = encoder block n, enc_ptrs[1 + enc_layers] = encoder output (+ speaker); dec_ptrs[0] = length

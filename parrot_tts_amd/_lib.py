@@ -69,6 +69,7 @@ SIGNATURES = {
     "parrot_selftest": (C.c_int, [vp]),
     "parrot_set_default_precision": (C.c_int, [i32]),
     "parrot_set_fused_resblocks": (C.c_int, [i32]),
+    "parrot_set_tte_merge": (C.c_int, [i32]),
     "parrot_conv_create": (C.c_int, [C.POINTER(vp), C.POINTER(ConvDesc), c_float_p, c_float_p]),
     "parrot_conv_destroy": (None, [vp]),
     "parrot_conv_run": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
@@ -79,7 +80,10 @@ SIGNATURES = {
     "parrot_prof_begin": (C.c_int, []),
     "parrot_prof_end": (C.c_int, [C.POINTER(C.c_double), i32]),
     "parrot_voc_create": (C.c_int, [C.POINTER(vp), C.POINTER(VocCfg), C.POINTER(VocWeights)]),
+    "parrot_voc_create_ex": (C.c_int, [C.POINTER(vp), C.POINTER(VocCfg), C.POINTER(VocWeights), i32, i32]),
     "parrot_voc_destroy": (None, [vp]),
+    "parrot_voc_precision": (C.c_int, [vp]),
+    "parrot_voc_debug_absmax": (C.c_int, [vp, vp]),
     "parrot_voc_workspace_bytes": (sz, [vp, i32, i32]),
     "parrot_voc_forward": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, C.POINTER(vp), vp, sz, vp]),
     "parrot_voc_forward_feats": (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, vp, C.POINTER(vp), vp, sz, vp]),
@@ -87,17 +91,22 @@ SIGNATURES = {
     "parrot_voc_forward_chunked": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "parrot_voc_check": (C.c_int, [vp, vp]),
     "parrot_voc_status_async": (C.c_int, [vp, vp, vp]),
+    "parrot_voc_status_peek_async": (C.c_int, [vp, vp, vp]),
     "parrot_voc_receptive_units": (C.c_int, [vp]),
     "parrot_voc_out_len": (C.c_int64, [vp, i32]),
     "parrot_wav_to_int16": (C.c_int, [vp, vp, sz, vp]),
     "parrot_tte_create": (C.c_int, [C.POINTER(vp), C.POINTER(TteCfg), C.POINTER(TteWeights)]),
+    "parrot_tte_create_ex": (C.c_int, [C.POINTER(vp), C.POINTER(TteCfg), C.POINTER(TteWeights), i32, i32]),
     "parrot_tte_destroy": (None, [vp]),
+    "parrot_tte_precision": (C.c_int, [vp]),
+    "parrot_tte_guard_logits": (C.c_int, [vp, vp, vp, i32, vp]),
     "parrot_tte_state_bytes": (sz, [vp, i32, i32]),
     "parrot_tte_workspace_bytes": (sz, [vp, i32, i32, i32]),
     "parrot_tte_encode": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_decode": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_check": (C.c_int, [vp, vp]),
     "parrot_tte_status_async": (C.c_int, [vp, vp, vp]),
+    "parrot_tte_status_peek_async": (C.c_int, [vp, vp, vp]),
     "parrot_tte_guard_stats_async": (C.c_int, [vp, vp, vp]),
     "parrot_tte_debug_stages": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "parrot_length_regulator_workspace_bytes": (sz, [i32, i32, i32, i32]),
@@ -122,7 +131,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.parrot_abi_version() != 3:
+        if handle.parrot_abi_version() != 4:
             raise ImportError("libparrot_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -386,16 +386,35 @@ static __global__ __launch_bounds__(64 * ARGMAX_WAVES) void argmax_cf_kernel(con
 // One workgroup per guarded position: logits[v] = head_b[v] + sum_c head_w[v][c] * x[b][c][t] in fp64 (exact products, fp64
 // sums in channel order: the argmax no longer depends on the accumulation order of the fp32 head), first maximum wins.
 // `hwt` is the head weight TRANSPOSED to (D, V): thread v reads hwt[c][v], coalesced across the workgroup.
+// Deep form (f != NULL; round 4): the position's activation is first re-evaluated one layer earlier, from the last decoder block's
+// own fp32 intermediates -- x[c] = h[c] + b2[c] + sum_j w2t[j][c] * f[j] in fp64 (f = relu(conv1) (B, F, L), h = x + attn (B, D, L),
+// w2t the 1x1 conv2's weight as (F, D): reference modules/fft.py:81,99) -- which removes the fp32 accumulation error of that
+// K = F sum and of the residual add from the refined logits.  `gref` (TIE_GUARD_MAX x V) receives the refined logits.
 static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const float* __restrict__ x, const float* __restrict__ hwt,
                                                                       const float* __restrict__ hb, int64_t* __restrict__ ids, int D, int V,
-                                                                      int L, const int* __restrict__ glist, int* __restrict__ gstat) {
+                                                                      int L, const int* __restrict__ glist, int* __restrict__ gstat,
+                                                                      const float* __restrict__ f, const float* __restrict__ h,
+                                                                      const float* __restrict__ w2t, const float* __restrict__ b2, int F,
+                                                                      float* __restrict__ gref) {
     const int n = min(gstat[0], TIE_GUARD_MAX);
     if ((int)blockIdx.x >= n) return;
-    extern __shared__ double xs[];  // D activations of the position
+    extern __shared__ double xs[];  // D activations of the position (+ F intermediates in the deep form)
     __shared__ double rv[256];
     __shared__ int ri[256];
     const int b = glist[2 * blockIdx.x], t = glist[2 * blockIdx.x + 1];
-    for (int c = threadIdx.x; c < D; c += 256) xs[c] = (double)x[((size_t)b * D + c) * L + t];
+    if (f) {
+        double* fs = xs + D;
+        for (int j = threadIdx.x; j < F; j += 256) fs[j] = (double)f[((size_t)b * F + j) * L + t];
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            double a = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < F; ++j) a = fma((double)w2t[(size_t)j * D + c], fs[j], a);
+            xs[c] = (a + (b2 ? (double)b2[c] : 0.0)) + (double)h[((size_t)b * D + c) * L + t];  // (conv + bias) + residual, fft.py:99
+        }
+    } else {
+        for (int c = threadIdx.x; c < D; c += 256) xs[c] = (double)x[((size_t)b * D + c) * L + t];
+    }
     __syncthreads();
     double best = -INFINITY;
     int bi = 0x7fffffff;
@@ -419,6 +438,7 @@ static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const floa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double a = acc[q] + (hb ? (double)hb[vv[q]] : 0.0);
+            if (ok[q] && gref) gref[(size_t)blockIdx.x * V + vv[q]] = (float)a;
             if (ok[q] && a > best) { best = a; bi = vv[q]; }  // (codes ascending per thread: the first maximum is kept)
         }
     }
@@ -460,6 +480,17 @@ static __global__ __launch_bounds__(256) void transpose_cf_to_cl_kernel(const fl
 static __global__ void wav_to_int16_kernel(const float* __restrict__ w, int16_t* __restrict__ o, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = (int16_t)(int32_t)(w[i] * 32768.0f);
+}
+
+// max |x[i]| -> atomic max into dst[0] (non-negative floats order like their bit patterns); NaN / inf count as +inf
+static __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ dst) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = fabsf(x[i]);
+        m = (v > m || !(v == v)) ? (v == v ? v : INFINITY) : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(m));
 }
 
 static __global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) {

@@ -631,6 +631,7 @@ struct parrot_voc {
     std::mutex side_mu;  // the side streams / events are the handle's: concurrent callers enqueue their fork-join sequences one at a time
     hipStream_t side[PARROT_MAX_KERNELS] = {};
     hipEvent_t ev_fork = nullptr, ev_last[PARROT_MAX_KERNELS] = {};
+    float* dbg_absmax = nullptr;       // parrot_voc_debug_absmax: (n_stages + 2) device floats, max |conv input| per group (caller-owned)
     ~parrot_voc() {
         for (hipStream_t q : side)
             if (q) (void)hipStreamDestroy(q);
@@ -663,7 +664,30 @@ static int make_conv(std::unique_ptr<parrot_conv>& slot, int cin, int cout, int 
     return PARROT_OK;
 }
 
+static int voc_create_impl(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w, int prec, int fused);
 extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w) {
+    return voc_create_impl(out, cfg, w, -1, -1);
+}
+extern "C" int parrot_voc_create_ex(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w, int32_t precision,
+                                    int32_t fused_resblocks) {
+    if (precision > PARROT_PREC_F16 || fused_resblocks > 2) return fail(PARROT_E_INVALID, "voc_create_ex: precision in -1 .. 4, fused_resblocks in -1 .. 2");
+    return voc_create_impl(out, cfg, w, precision, fused_resblocks);
+}
+// (the conv plans read the precision from the process default at build time: the per-handle value is installed around the
+//  build under a mutex, so concurrent creates with different precisions do not see each other's)
+static std::mutex g_create_mu;
+static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w);
+static int voc_create_impl(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w, int prec, int fused) {
+    std::lock_guard<std::mutex> lk(g_create_mu);
+    const int prec0 = default_prec(), fused0 = fused_mode();
+    if (prec >= 0) g_default_prec.store(prec);
+    if (fused >= 0) g_fused.store(fused);
+    const int r = voc_create_body(out, cfg, w);
+    g_default_prec.store(prec0);
+    g_fused.store(fused0);
+    return r;
+}
+static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w) {
     if (!out || !cfg || !w) return fail(PARROT_E_INVALID, "voc_create: null argument");
     if (cfg->n_stages <= 0 || cfg->n_stages > PARROT_MAX_STAGES || cfg->n_kernels <= 0 || cfg->n_kernels > PARROT_MAX_KERNELS ||
         cfg->n_dil <= 0 || cfg->n_dil > PARROT_MAX_DIL || (cfg->resblock_type != 1 && cfg->resblock_type != 2))
@@ -799,6 +823,16 @@ extern "C" int parrot_voc_create(parrot_voc_t** out, const parrot_voc_cfg* cfg, 
     return PARROT_OK;
 }
 extern "C" void parrot_voc_destroy(parrot_voc_t* v) { delete v; }
+extern "C" int parrot_voc_precision(const parrot_voc_t* v) { return v ? v->scheme : PARROT_E_INVALID; }
+// Debug aid (range headroom of the fp16 split scheme, |x| < 8190): while dst_dev != NULL every conv launched by
+// parrot_voc_forward records max |input element| into dst_dev[group] (atomic max; group 0 = conv_pre, 1 + i = the layers of
+// stage i (ups_i and its ResBlocks), n_stages + 1 = conv_post).  Fused ResBlock launches only see their block's input: create the
+// handle with fused_resblocks = 0 (parrot_voc_create_ex) to cover every layer.  The caller zeroes the n_stages + 2 floats.
+extern "C" int parrot_voc_debug_absmax(parrot_voc_t* v, float* dst_dev) {
+    if (!v) return fail(PARROT_E_INVALID, "voc_debug_absmax: null handle");
+    v->dbg_absmax = dst_dev;
+    return PARROT_OK;
+}
 
 static size_t voc_max_act(const parrot_voc* v, int B, int U) {
     size_t mx = (size_t)B * v->cfg.upsample_initial_channel * U;
@@ -1084,10 +1118,18 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         if (stage_out && stage_out[idx]) HIP_TRY(hipMemcpyAsync(stage_out[idx], src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         return PARROT_OK;
     };
+    auto amax = [&](int group, const float* src, size_t n, hipStream_t q) -> int {  // debug: max |conv input| per layer group
+        if (v->dbg_absmax) {
+            hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, q, src, n, v->dbg_absmax + group);
+            HIP_TRY(hipGetLastError());
+        }
+        return PARROT_OK;
+    };
     int ia = 0;
     // unit_lens (optional): per-row number of real units; every layer then applies ITS zero padding at the row's own
     // end (row_len * samples-per-unit so far), so a padded batch row equals the reference's B=1 run of that utterance
     int mul = 1, add = 0;  // a row of n units holds n * mul + add samples at the current layer
+    TRY(amax(0, x0, (size_t)B * c.model_in_dim * U, s));
     TRY(conv_launch(v->conv_pre.get(), x0, nullptr, P[ia], B, U, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul, add));
     TRY(snap(0, P[ia], (size_t)B * c.upsample_initial_channel * U));
     int T = U;
@@ -1097,6 +1139,7 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         float* A = P[ia];
         float* X = P[(ia + 1) % 3];
         float* XS = P[(ia + 2) % 3];
+        TRY(amax(1 + i, A, (size_t)B * (c.upsample_initial_channel >> i) * T, s));
         TRY(conv_launch(v->ups[i].get(), A, nullptr, X, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul, add));
         T = v->ups[i]->out_len(T);
         mul *= c.upsample_rates[i];
@@ -1122,6 +1165,7 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
             // (which kernel family runs a block never depends on the batch size or on the launch size: row b of a batch must equal
             //  the same utterance run alone BIT FOR BIT -- the batched driver's byte-identical WAVs rest on it.  At B = 1 the
             //  96-column windows of the 128- / 256-channel pair kernels are only 16-61 workgroups: 3.4 instead of 3.2 ms per utterance)
+            if (j == 0) TRY(amax(1 + i, X, n_act, s));  // the stage input feeds the first conv of every branch
             if (v->fused != 0 && v->rb_stream[(size_t)i * nk + j] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {
                 TRY(resblock_split_launch(v, i, j, X, XS, RA, RB, B, T, epi_last, (float)nk, sj, unit_lens, mul, add, order));
             } else if (resblock_fusable(v, i, j)) {
@@ -1130,8 +1174,11 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
                 for (int m = 0; m < nd; ++m) {
                     const bool last = (m == nd - 1);
                     float* dst = last ? XS : ((m & 1) ? RB : RA);
-                    if (c.resblock_type == 1)
+                    if (m > 0) TRY(amax(1 + i, r, n_act, sj));
+                    if (c.resblock_type == 1) {
                         TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, sj, unit_lens, mul, add));
+                        TRY(amax(1 + i, T1, n_act, sj));
+                    }
                     if (last && order) HIP_TRY(hipStreamWaitEvent(sj, order, 0));
                     if (c.resblock_type == 1)
                         TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul, add));
@@ -1147,6 +1194,7 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         TRY(snap(2 + 2 * i, XS, n_act));
         ia = (ia + 2) % 3;
     }
+    TRY(amax(1 + c.n_stages, P[ia], (size_t)B * v->chan(c.n_stages - 1) * T, s));
     TRY(conv_launch(v->conv_post.get(), P[ia], nullptr, wav_out, B, T, EPI_STORE, 1.f, 0, 0, 0, s, unit_lens, mul, add));
     return PARROT_OK;
 }
@@ -1188,8 +1236,14 @@ struct parrot_tte {
     float *head_w = nullptr, *head_b = nullptr;
     int *glist = nullptr, *gstat = nullptr;
     float guard = 1e-4f;
+    // ... extended to the last decoder block's FFN output (round 4): for a guarded position the block's conv2 (1x1) + bias +
+    // residual are re-evaluated in fp64 from the fp32 activations the block itself produced (relu(conv1) and x + attn), then the
+    // head: last_w2t = that conv2's weight transposed to (F, D), last_b2 its bias; gref = the refined logits of the guarded
+    // positions of the last decode (TIE_GUARD_MAX x V floats, parrot_tte_guard_logits)
+    float *last_w2t = nullptr, *last_b2 = nullptr, *gref = nullptr;
+    bool merged = true;
     ~parrot_tte() {
-        for (float* p : {pe, tok, spk, ln0_w, ln0_b, ln1_w, ln1_b, head_w, head_b})
+        for (float* p : {pe, tok, spk, ln0_w, ln0_b, ln1_w, ln1_b, head_w, head_b, last_w2t, last_b2, gref})
             if (p) (void)hipFree(p);
         if (err) (void)hipFree(err);
         if (glist) (void)hipFree(glist);
@@ -1197,6 +1251,22 @@ struct parrot_tte {
     }
 };
 
+// Default for handles created afterwards: fold the back-to-back bias-free projections of an FFT block (quirk Q3) into one each.
+// PARROT_TTE_MERGE / parrot_set_tte_merge; parrot_tte_create_ex overrides it per handle.
+static std::atomic<int> g_tte_merge{-1};
+static int tte_merge_default() {
+    int v = g_tte_merge.load();
+    if (v < 0) {
+        const char* e = getenv("PARROT_TTE_MERGE");
+        v = (!e || atoi(e) != 0) ? 1 : 0;
+        g_tte_merge.store(v);
+    }
+    return v;
+}
+extern "C" int parrot_set_tte_merge(int32_t on) {
+    g_tte_merge.store(on ? 1 : 0);
+    return PARROT_OK;
+}
 static int build_fft(std::unique_ptr<FftLayer>& slot, const parrot_tte_cfg& c, int heads, const parrot_fft_weights& w) {
     std::unique_ptr<FftLayer> L(new FftLayer());
     const int D = c.d_model, F = c.n_filter_ffn;
@@ -1207,7 +1277,7 @@ static int build_fft(std::unique_ptr<FftLayer>& slot, const parrot_tte_cfg& c, i
     // nothing in between are ONE linear map: the products are formed here in fp64 and rounded once to fp32
     //     W_qkv' = blockdiag(W_in_q, W_in_k, W_in_v) * W_qkv   (3D x D),     W_o' = W_wo * W_out   (D x D)
     // which removes two launches per block (PARROT_TTE_MERGE=0 keeps the four separate projections).
-    static const bool merge = [] { const char* e = getenv("PARROT_TTE_MERGE"); return !e || atoi(e) != 0; }();
+    const bool merge = tte_merge_default() != 0;
     L->merged = merge;
     if (merge) {
         std::vector<float> wq((size_t)3 * D * D), wo((size_t)D * D);
@@ -1254,7 +1324,27 @@ static int build_fft(std::unique_ptr<FftLayer>& slot, const parrot_tte_cfg& c, i
     return PARROT_OK;
 }
 
+static int tte_create_body(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w);
+static int tte_create_impl(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w, int prec, int merge) {
+    std::lock_guard<std::mutex> lk(g_create_mu);
+    const int prec0 = default_prec(), merge0 = tte_merge_default();
+    if (prec >= 0) g_default_prec.store(prec);
+    if (merge >= 0) g_tte_merge.store(merge ? 1 : 0);
+    const int r = tte_create_body(out, cfg, w);
+    g_default_prec.store(prec0);
+    g_tte_merge.store(merge0);
+    return r;
+}
 extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w) {
+    return tte_create_impl(out, cfg, w, -1, -1);
+}
+extern "C" int parrot_tte_create_ex(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w, int32_t precision,
+                                    int32_t merge_projections) {
+    if (precision > PARROT_PREC_F16 || merge_projections > 1) return fail(PARROT_E_INVALID, "tte_create_ex: precision in -1 .. 4, merge_projections in -1 .. 1");
+    return tte_create_impl(out, cfg, w, precision, merge_projections);
+}
+extern "C" int parrot_tte_precision(const parrot_tte_t* t) { return t ? t->scheme : PARROT_E_INVALID; }
+static int tte_create_body(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w) {
     if (!out || !cfg || !w) return fail(PARROT_E_INVALID, "tte_create: null argument");
     const parrot_tte_cfg& c = *cfg;
     if (c.d_model <= 0 || c.n_filter_ffn <= 0 || c.max_len <= 0 || c.vocab <= 0 || c.n_codes <= 0 || c.dp_filter <= 0 ||
@@ -1290,6 +1380,7 @@ extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, 
     TRY(upload(&t->ln0_b, w->dp_ln0_b, c.dp_filter));
     TRY(upload(&t->ln1_w, w->dp_ln1_w, c.dp_filter));
     TRY(upload(&t->ln1_b, w->dp_ln1_b, c.dp_filter));
+    t->merged = tte_merge_default() != 0;
     t->enc.resize(c.enc_layers);
     t->dec.resize(c.dec_layers);
     for (int i = 0; i < c.enc_layers; ++i) TRY(build_fft(t->enc[i], c, c.enc_heads, w->enc[i]));
@@ -1305,6 +1396,16 @@ extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, 
             TRY(upload(&t->head_w, wt.data(), wt.size()));
         }
         if (w->head_b) TRY(upload(&t->head_b, w->head_b, (size_t)c.n_codes));
+        if (c.dec_layers > 0 && c.ffn_k2 == 1) {  // deep guard: the last decoder block's conv2 as (F, D) + its bias
+            const parrot_fft_weights& lw = w->dec[c.dec_layers - 1];
+            const int F = c.n_filter_ffn;
+            std::vector<float> wt((size_t)F * D);
+            for (int o = 0; o < D; ++o)
+                for (int j = 0; j < F; ++j) wt[(size_t)j * D + o] = lw.conv2_w[(size_t)o * F + j];
+            TRY(upload(&t->last_w2t, wt.data(), wt.size()));
+            if (lw.conv2_b) TRY(upload(&t->last_b2, lw.conv2_b, (size_t)D));
+        }
+        HIP_TRY(hipMalloc((void**)&t->gref, (size_t)TIE_GUARD_MAX * c.n_codes * sizeof(float)));
         HIP_TRY(hipMalloc((void**)&t->glist, 2 * TIE_GUARD_MAX * sizeof(int)));
         HIP_TRY(hipMalloc((void**)&t->gstat, 4 * sizeof(int)));
         HIP_TRY(hipMemset(t->gstat, 0, 4 * sizeof(int)));
@@ -1511,8 +1612,13 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
                            on ? t->glist : nullptr, on ? t->gstat : nullptr);
         HIP_TRY(hipGetLastError());
         if (on) {  // re-evaluate the head of the low-margin positions in fp64 (workgroups beyond the count exit at once)
-            hipLaunchKernelGGL(tie_guard_refine_kernel, dim3(TIE_GUARD_MAX), dim3(256), (size_t)D * sizeof(double), s, w.x, t->head_w, t->head_b,
-                               ids, D, V, L, t->glist, t->gstat);
+            // w.f / w.h still hold the last decoder block's relu(conv1) and x + attn: with them the refinement starts one layer
+            // earlier (conv2 + bias + residual in fp64, then the head); without a decoder block it starts at w.x
+            const bool deep = t->last_w2t != nullptr && !t->dec.empty();
+            const int F = c.n_filter_ffn;
+            hipLaunchKernelGGL(tie_guard_refine_kernel, dim3(TIE_GUARD_MAX), dim3(256), (size_t)(D + (deep ? F : 0)) * sizeof(double), s, w.x,
+                               t->head_w, t->head_b, ids, D, V, L, t->glist, t->gstat, deep ? w.f : nullptr, deep ? w.h : nullptr, t->last_w2t,
+                               t->last_b2, F, t->gref);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1664,6 +1770,17 @@ static int status_async(int* err, int32_t* dst_dev, hipStream_t s) {
     return PARROT_OK;
 }
 extern "C" int parrot_voc_status_async(parrot_voc_t* v, int32_t* dst_dev, void* stream) { return v ? status_async(v->err, dst_dev, (hipStream_t)stream) : PARROT_E_INVALID; }
+// ... and without clearing it (the shims' first-forward range probe: a bad-id flag stays for the regular reporting path)
+extern "C" int parrot_voc_status_peek_async(parrot_voc_t* v, int32_t* dst_dev, void* stream) {
+    if (!v || !dst_dev) return fail(PARROT_E_INVALID, "voc_status_peek: null argument");
+    HIP_TRY(hipMemcpyAsync(dst_dev, v->err, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PARROT_OK;
+}
+extern "C" int parrot_tte_status_peek_async(parrot_tte_t* t, int32_t* dst_dev, void* stream) {
+    if (!t || !dst_dev) return fail(PARROT_E_INVALID, "tte_status_peek: null argument");
+    HIP_TRY(hipMemcpyAsync(dst_dev, t->err, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PARROT_OK;
+}
 extern "C" int parrot_tte_status_async(parrot_tte_t* t, int32_t* dst_dev, void* stream) { return t ? status_async(t->err, dst_dev, (hipStream_t)stream) : PARROT_E_INVALID; }
 // Tie-guard statistics of the last decode, copied to dst_dev[0..2] (device memory) on `stream` without synchronising:
 // {positions whose top-2 logit margin was below the guard, ids changed by the fp64 re-evaluation of the head, the smallest
@@ -1671,6 +1788,16 @@ extern "C" int parrot_tte_status_async(parrot_tte_t* t, int32_t* dst_dev, void* 
 extern "C" int parrot_tte_guard_stats_async(parrot_tte_t* t, int32_t* dst_dev, void* stream) {
     if (!t || !dst_dev) return fail(PARROT_E_INVALID, "tte_guard_stats: null argument");
     HIP_TRY(hipMemcpyAsync(dst_dev, t->gstat, 3 * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PARROT_OK;
+}
+// Refined (fp64-evaluated, rounded to fp32) logits of the guarded positions of the last decode: logits_dev (max_n x V floats) and
+// their (b, t) pairs list_dev (2 max_n ints), device memory, no synchronisation; the count is guard_stats[0] (capped at 256).
+extern "C" int parrot_tte_guard_logits(parrot_tte_t* t, float* logits_dev, int32_t* list_dev, int32_t max_n, void* stream) {
+    if (!t || !logits_dev || !list_dev || max_n <= 0) return fail(PARROT_E_INVALID, "tte_guard_logits: null argument");
+    if (!t->gref) return fail(PARROT_E_UNSUPPORTED, "tte_guard_logits: the tie guard of this handle is off");
+    const int n = std::min<int>(max_n, TIE_GUARD_MAX);
+    HIP_TRY(hipMemcpyAsync(logits_dev, t->gref, (size_t)n * t->cfg.n_codes * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(list_dev, t->glist, (size_t)2 * n * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PARROT_OK;
 }
 extern "C" int parrot_voc_check(parrot_voc_t* v, void* stream) { return v ? read_flag(v->err, (hipStream_t)stream, "vocoder") : PARROT_E_INVALID; }

@@ -17,6 +17,7 @@ EPI_STORE, EPI_ADD, EPI_ADD_DIV = 0, 1, 2
 PREC_F32, PREC_BF16X6, PREC_F16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3, 4
 PREC_NAMES = {"f32": PREC_F32, "bf16x6": PREC_BF16X6, "f16x3": PREC_F16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 PREC_DEFAULT = PREC_F16X3
+PREC_STR = {v: k for k, v in PREC_NAMES.items()}
 
 
 def set_default_precision(prec: int) -> None:
@@ -30,6 +31,19 @@ def set_fused_resblocks(mode: int) -> None:
     """ResBlocks through the fused LDS-resident kernels: 0 off, 1 every eligible stage, 2 all but the exact-fp32
     32-channel kernel (library default).  Applies to handles created afterwards."""
     _lib.check(_lib.lib().parrot_set_fused_resblocks(int(mode)))
+
+
+def set_tte_merge(on: bool) -> None:
+    """FFT blocks: evaluate the back-to-back bias-free projections (quirk Q3) as their fp64-formed product (True, library
+    default) or one after the other as the reference does.  Applies to handles created afterwards."""
+    _lib.check(_lib.lib().parrot_set_tte_merge(int(bool(on))))
+
+
+def range_fallback_default() -> bool:
+    """PARROT_RANGE_FALLBACK (default on): a handle whose first forward reports a non-finite result under the default fp16x3
+    scheme (|activation| >= 8190) is rebuilt in bf16x6 (fp32's range) and the batch re-run, with a warning."""
+    import os
+    return os.environ.get("PARROT_RANGE_FALLBACK", "1") not in ("", "0")
 
 
 def stream_ptr(device=None) -> C.c_void_p:

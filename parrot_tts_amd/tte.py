@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import dptr, param_fingerprint, require_cuda, stream_ptr
+from .ops import PREC_BF16X6, PREC_F16X3, PREC_STR, dptr, param_fingerprint, range_fallback_default, require_cuda, stream_ptr
 from .synth import sinusoid_table
 
 
@@ -100,6 +100,12 @@ class Parrot(nn.Module):
         self._handle: Optional[C.c_void_p] = None
         self._handle_device = None
         self._handle_fp = None
+        # range-safe fallback (see CodeGenerator): the first decode of every new handle is checked synchronously; non-finite logits
+        # under the default fp16x3 scheme rebuild the handle in bf16x6 and re-run the batch, with a warning
+        self.range_fallback = range_fallback_default()
+        self._precision_override: Optional[int] = None
+        self._merge_override: Optional[bool] = None  # None: library default (merged); tests build unmerged handles beside it
+        self._probe_pending = False
         # torch's load_state_dict recurses through _load_from_state_dict and never calls a CHILD's load_state_dict
         # override, so a reload through any wrapper (LitParrot, nn.Sequential ...) is caught here: the post hook runs
         # for every module of the tree, and _current_handle() also compares the parameters' version fingerprint.
@@ -163,8 +169,29 @@ class Parrot(nn.Module):
         w.head_w, w.head_b = P("head.weight"), P("head.bias")
         hdl = C.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(_lib.lib().parrot_tte_create(C.byref(hdl), C.byref(cfg), C.byref(w)))
+            _lib.check(_lib.lib().parrot_tte_create_ex(C.byref(hdl), C.byref(cfg), C.byref(w),
+                                                       -1 if self._precision_override is None else self._precision_override,
+                                                       -1 if self._merge_override is None else int(self._merge_override)))
         self._handle, self._handle_device = hdl, device
+        self._probe_pending = True
+
+    @property
+    def precision_in_use(self) -> Optional[str]:
+        """Precision of the live handle ("f16x3", "bf16x6", ...; None before the first forward)."""
+        if self._handle is None:
+            return None
+        return PREC_STR.get(int(_lib.lib().parrot_tte_precision(self._handle)))
+
+    def _fall_back(self, why: str) -> bool:
+        import warnings
+        cur = None if self._handle is None else int(_lib.lib().parrot_tte_precision(self._handle))
+        if not self.range_fallback or cur != PREC_F16X3:
+            return False
+        warnings.warn(f"parrot_tts_amd TTE: {why}: an activation left the fp16x3 scheme's range (|x| < 8190); rebuilding the handle in "
+                      "bf16x6 (fp32's range) for this and all later batches.", RuntimeWarning, stacklevel=3)
+        self._precision_override = PREC_BF16X6
+        self._invalidate()
+        return True
 
     # ---- forward ------------------------------------------------------------------------------
     @staticmethod
@@ -206,13 +233,18 @@ class Parrot(nn.Module):
                 _lib.check(lib.parrot_tte_encode(self._handle, dptr(phones), dptr(valid), dptr(speaker), B, S, dptr(log_dur), dptr(dur),
                                                  dptr(lens), dptr(state), state.numel(), dptr(ws), ws.numel(), st))
                 _lib.check(lib.parrot_tte_status_async(self._handle, status.data_ptr() + 4 * B, st))
-                names = [hook(status.data_ptr() + 4 * (B + 1 + i), st) for i, hook in enumerate(status_hooks)]
+                hooked = [hook(status.data_ptr() + 4 * (B + 1 + i), st) for i, hook in enumerate(status_hooks)]
+                hooked = [h if isinstance(h, tuple) else (h, None) for h in hooked]  # (name, on_nonfinite callback or None)
                 status_h = status.cpu()  # the one host sync the reference also has (duration.py:10)
                 lens_h = status_h[:B]
                 # bad phone / speaker ids of THIS encode (the reference's Embedding IndexError), non-finite logits of the previous
                 # decode, and whatever the hooks watch (the previous vocoder forward): raised here, by default, at no extra sync
+                if int(status_h[B]) == 5:
+                    self._fall_back("a previous decode produced non-finite logits")  # (later batches run in bf16x6; this one is reported)
                 self._raise_status(int(status_h[B]), "tte")
-                for i, nm in enumerate(names):
+                for i, (nm, on_nonfinite) in enumerate(hooked):
+                    if int(status_h[B + 1 + i]) == 5 and on_nonfinite is not None:
+                        on_nonfinite()
                     self._raise_status(int(status_h[B + 1 + i]), nm)
                 L = int(lens_h.max())
                 del ws
@@ -222,6 +254,15 @@ class Parrot(nn.Module):
                 logits = torch.empty((B, L, lib_n_codes(self)), dtype=torch.float32, device=dev) if want_logits else None
                 _lib.check(lib.parrot_tte_decode(self._handle, B, S, L, dptr(ids), dptr(tgt), dptr(logits), dptr(state), state.numel(),
                                                  dptr(ws), ws.numel(), st))
+                if self._probe_pending:  # first decode of this handle: one synchronous look at the device flag
+                    self._probe_pending = False
+                    if self.range_fallback and int(lib.parrot_tte_precision(self._handle)) == PREC_F16X3:
+                        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+                        _lib.check(lib.parrot_tte_status_peek_async(self._handle, dptr(flag), st))
+                        if int(flag.cpu()) == 5:
+                            _lib.check(lib.parrot_tte_status_async(self._handle, dptr(flag), st))  # handled here: clear it
+                            if self._fall_back("the first decode of this handle produced non-finite logits"):
+                                return self._run(batch, want_logits, status_hooks=())
             except _lib.ParrotHipError as e:
                 if e.code == -2:  # PARROT_E_RANGE <-> the reference's IndexError (pe[T], Embedding)
                     raise IndexError(str(e)) from None
@@ -271,7 +312,21 @@ class Parrot(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().parrot_tte_guard_stats_async(self._handle, buf.data_ptr(), stream_ptr(dev)))
         n, changed, bits = (int(v) for v in buf.cpu())
-        return {"n_guarded": n, "min_margin": struct.unpack("f", struct.pack("i", bits))[0], "ids_changed": changed}
+        return {"n_guarded": n, "min_margin": struct.unpack("f", struct.pack("i", bits))[0], "ids_changed": changed,
+                "precision_in_use": self.precision_in_use}
+
+    def guard_logits(self, max_n: int = 256):
+        """Tests / parity reports: the refined logits of the guarded positions of the last decode (fp64 re-evaluation of the last
+        decoder block's conv2 + bias + residual and of the head, rounded to fp32) -> (logits (n, V), positions (n, 2) as (b, t))."""
+        dev = self._handle_device
+        n = min(self.guard_stats()["n_guarded"], max_n, 256)
+        V = lib_n_codes(self)
+        lg = torch.empty((max(n, 1), V), dtype=torch.float32, device=dev)
+        pos = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().parrot_tte_guard_logits(self._handle, dptr(lg), dptr(pos), max(n, 1), stream_ptr(dev)))
+        torch.cuda.synchronize(dev)
+        return lg[:n].cpu(), pos[:n].cpu()
 
     def check_outputs(self) -> None:
         """Synchronise and raise FloatingPointError if the last decode produced NaN / inf logits (an activation beyond the

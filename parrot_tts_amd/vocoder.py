@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import dptr, param_fingerprint, require_cuda, stream_ptr
+from .ops import PREC_BF16X6, PREC_F16X3, PREC_STR, dptr, param_fingerprint, range_fallback_default, require_cuda, stream_ptr
 
 
 class AttrDict(dict):
@@ -145,6 +145,12 @@ class CodeGenerator(nn.Module):
         self._handle_device = None
         self._handle_fp = None
         self._ws: Dict[tuple, torch.Tensor] = {}
+        # range-safe fallback: the default fp16x3 scheme needs |activation| < 8190, which no checkpoint format promises.  The FIRST
+        # forward of every new handle is checked synchronously (one sync per handle lifetime); a non-finite result rebuilds the
+        # handle in bf16x6 (fp32's range), re-runs the batch and warns.  Later forwards are covered by the asynchronous flag.
+        self.range_fallback = range_fallback_default()
+        self._precision_override: Optional[int] = None  # PARROT_PREC_* this module's handles are created with (None: library default)
+        self._probe_pending = False
         # a reload through a parent module never reaches a child's load_state_dict override: invalidate from the post
         # hook torch runs for every module of the tree, and compare the parameter fingerprint before each forward
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
@@ -187,7 +193,7 @@ class CodeGenerator(nn.Module):
             pass
 
     # ---- HIP handle ---------------------------------------------------------------------------
-    def _build(self, device):
+    def _build(self, device, fused=None, debug_handle=False):
         if self._in_dim < self._emb_dim * (2 if self.multispkr else 1):
             raise ValueError("model_in_dim is smaller than embedding_dim * (1 + multispkr)")
         cfg = _lib.VocCfg()
@@ -225,8 +231,53 @@ class CodeGenerator(nn.Module):
         w.conv_post_w, w.conv_post_b = host(self.conv_post.folded()), host(self.conv_post.bias)
         hdl = C.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(_lib.lib().parrot_voc_create(C.byref(hdl), C.byref(cfg), C.byref(w)))
+            _lib.check(_lib.lib().parrot_voc_create_ex(C.byref(hdl), C.byref(cfg), C.byref(w),
+                                                       -1 if self._precision_override is None else self._precision_override,
+                                                       -1 if fused is None else int(fused)))
+        if debug_handle:
+            return hdl
         self._handle, self._handle_device = hdl, device
+        self._probe_pending = True
+
+    @property
+    def precision_in_use(self) -> Optional[str]:
+        """Precision of the live handle ("f16x3", "bf16x6", ...; None before the first forward): "bf16x6" after the range-safe
+        fallback replaced a default-precision handle."""
+        if self._handle is None:
+            return None
+        return PREC_STR.get(int(_lib.lib().parrot_voc_precision(self._handle)))
+
+    def _first_forward_overflowed(self, dev) -> bool:
+        """After the FIRST forward of a handle: one synchronous look at the device flag; True = the handle was replaced by a
+        bf16x6 one and the caller re-runs its batch.  (A bad-id flag stays set for check_inputs() / the status hook.)"""
+        if not self._probe_pending:
+            return False
+        self._probe_pending = False
+        if not self.range_fallback:
+            return False
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            _lib.check(lib.parrot_voc_status_peek_async(self._handle, dptr(flag), stream_ptr(dev)))
+        if int(flag.cpu()) != 5 or int(lib.parrot_voc_precision(self._handle)) != PREC_F16X3:
+            return False  # (a bad-id flag, or a non-finite result with nothing to fall back to, stays set for check_inputs() / the hook)
+        with torch.cuda.device(dev):
+            _lib.check(lib.parrot_voc_status_async(self._handle, dptr(flag), stream_ptr(dev)))  # handled here: clear it
+        return self._fall_back("the first forward of this handle produced a non-finite waveform")
+
+    def _fall_back(self, why: str) -> bool:
+        """Switch this module to bf16x6 handles after a non-finite result under an fp16 scheme.  Returns False when there is
+        nothing to fall back to (already fp32-range, or the fallback is switched off)."""
+        import warnings
+        cur = None if self._handle is None else int(_lib.lib().parrot_voc_precision(self._handle))
+        if not self.range_fallback or cur not in (PREC_F16X3,):
+            return False
+        warnings.warn(f"parrot_tts_amd vocoder: {why}: an activation left the fp16x3 scheme's range (|x| < 8190); rebuilding the handle "
+                      "in bf16x6 (fp32's range, ~1.5x slower) for this and all later batches. CodeGenerator.activation_headroom() "
+                      "shows the per-stage maxima.", RuntimeWarning, stacklevel=3)
+        self._precision_override = PREC_BF16X6
+        self._invalidate()
+        return True
 
     @property
     def upsample_factor(self) -> int:
@@ -311,6 +362,8 @@ class CodeGenerator(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(lib.parrot_voc_forward_feats(self._handle, dptr(code), dptr(spkr), dptr(feats), n_feat, dptr(lens32), B, U,
                                                     dptr(wav), stage_ptrs, dptr(ws), ws.numel(), stream_ptr(dev)))
+        if self._first_forward_overflowed(dev):
+            return self.forward(stages=stages, unit_lens=unit_lens, **kwargs)
         if _CHECK_FINITE and not bool(torch.isfinite(wav).all()):
             # the default fp16x3 scheme needs |activation| < 8190 (include/parrot_hip.h): beyond that the output is inf/NaN
             raise FloatingPointError("non-finite waveform: an activation left the fp16 split scheme's range; "
@@ -326,12 +379,43 @@ class CodeGenerator(nn.Module):
         self._current_handle(dev)
         return int(_lib.lib().parrot_voc_receptive_units(self._handle))
 
-    def _status_hook(self, dst_ptr: int, stream: int) -> str:
+    def _status_hook(self, dst_ptr: int, stream: int):
         """Enqueue a copy of this handle's device status flag (bad ids / non-finite waveform of EARLIER forwards) to ``dst_ptr``
-        without synchronising: `Parrot._run` fetches it together with the expanded lengths."""
+        without synchronising: `Parrot._run` fetches it together with the expanded lengths.  Returns (name, on_nonfinite): the
+        callback switches this module to bf16x6 handles before the FloatingPointError is raised, so a retry succeeds."""
         if self._handle is not None:
             _lib.check(_lib.lib().parrot_voc_status_async(self._handle, dst_ptr, stream))
-        return "vocoder (previous forward)"
+        return "vocoder (previous forward)", lambda: self._fall_back("a previous forward produced a non-finite waveform")
+
+    @torch.no_grad()
+    def activation_headroom(self, **kwargs) -> dict:
+        """Debug aid for the fp16x3 range (|conv input| < 8190): runs ONE forward of these inputs on a temporary layer-by-layer
+        handle in this module's precision (bf16x6 when the default would overflow) that records max |input element| of every conv,
+        grouped as conv_pre / stage i / conv_post.  Returns {"max_abs": {...}, "headroom": {group: 8190 / max}, "limit": 8190.0}."""
+        code, spkr, lens32 = self._checked_inputs(kwargs, None)
+        dev = code.device
+        keep, self._precision_override = self._precision_override, (self._precision_override if self._precision_override is not None else PREC_BF16X6)
+        try:
+            hdl = self._build(dev, fused=0, debug_handle=True)
+        finally:
+            self._precision_override = keep
+        lib = _lib.lib()
+        try:
+            B, U = code.shape
+            n_groups = len(self._rates) + 2
+            amax = torch.zeros(n_groups, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.parrot_voc_workspace_bytes(hdl, B, U), dtype=torch.uint8, device=dev)
+            wav = torch.empty((B, 1, self.out_samples(U)), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.parrot_voc_debug_absmax(hdl, dptr(amax)))
+                _lib.check(lib.parrot_voc_forward(hdl, dptr(code), dptr(spkr), None, B, U, dptr(wav), None, dptr(ws), ws.numel(), stream_ptr(dev)))
+                _lib.check(lib.parrot_voc_debug_absmax(hdl, None))
+            vals = amax.cpu().tolist()
+        finally:
+            lib.parrot_voc_destroy(hdl)
+        names = ["conv_pre"] + [f"stage{i}" for i in range(len(self._rates))] + ["conv_post"]
+        return {"max_abs": dict(zip(names, vals)), "headroom": {n: (8190.0 / v if v > 0 else float("inf")) for n, v in zip(names, vals)},
+                "limit": 8190.0}
 
     @torch.no_grad()
     def stream(self, chunk_units: int = 256, halo_units: Optional[int] = None, unit_lens: Optional[torch.Tensor] = None, **kwargs):
@@ -382,6 +466,8 @@ class CodeGenerator(nn.Module):
             with torch.cuda.device(dev):
                 _lib.check(lib.parrot_voc_forward_chunked(self._handle, dptr(code), dptr(spkr), dptr(lens32), B, U, int(chunk_units), halo,
                                                           dptr(wav), dptr(ws), ws.numel(), stream_ptr(dev)))
+            if self._first_forward_overflowed(dev):
+                return self.forward_chunked(chunk_units=chunk_units, halo_units=halo_units, unit_lens=unit_lens, **kwargs)
             return wav
         out = torch.empty((code.shape[0], 1, code.shape[1] * self.upsample_factor), dtype=torch.float32, device=code.device)
         for first, wav in self.stream(chunk_units, halo_units, unit_lens=unit_lens, **kwargs):
@@ -416,6 +502,7 @@ class CodeGenerator(nn.Module):
                 if e.code == -2:
                     raise IndexError(str(e)) from None
                 if e.code == -6:
+                    self._fall_back("an earlier forward produced a non-finite waveform")  # (later forwards run in bf16x6)
                     raise FloatingPointError(str(e)) from None
                 raise
 

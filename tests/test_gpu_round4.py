@@ -12,7 +12,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import parrot_oracle as O  # noqa: E402
-from parrot_tts_amd import synth  # noqa: E402
+from parrot_tts_amd import ops, synth  # noqa: E402
+from parrot_tts_amd.pipeline import SynthesisPipeline  # noqa: E402
+from parrot_tts_amd.tte import Parrot  # noqa: E402
 from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
 
 DEV = "cuda:0"
@@ -75,3 +77,153 @@ def test_bench_rehearses_eight_ranks_on_one_gpu():
     assert abs(res["value"] * res["ms_per_step"] / 1e3 - 16 * 256 * 320) < 1.0
     assert 0.0 < res["gather_ms"] < res["ms_per_step"]
     assert "10-speaker" in res["config"]["note"]
+
+
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
+
+
+def _report(**kw):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+def _small_pipeline(tmp_path, vsd_patch=None):
+    cfg, h = synth.small_tte_config(), synth.small_voc_config()
+    cfg["path"]["root_path"] = str(tmp_path)
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({"a": 0, "b": 1}, f)
+    vocab, n_spk = 30, 2
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=31)
+    for k in list(tsd):  # the small vocoder knows 100 units
+        if k.endswith("head.weight") or k.endswith("head.bias"):
+            tsd[k] = tsd[k].clone()
+            tsd[k][100:] = -10.0 if k.endswith("bias") else 0.0
+    vsd = synth.synth_voc_state_dict(h, seed=3)
+    if vsd_patch:
+        vsd = vsd_patch(dict(vsd))
+    parrot = Parrot(cfg, vocab, 0)
+    parrot.load_state_dict(tsd)
+    batch = {k: v.to(DEV) for k, v in synth.synth_tte_batch(2, 9, vocab, n_spk, seed=1).items()}
+    return SynthesisPipeline(parrot.eval().to(DEV), _gen(h, vsd)), batch, h, vsd
+
+
+def test_range_safe_fallback_rebuilds_in_bf16x6_and_matches_the_oracle(tmp_path):
+    """the `conv_pre.bias + 3e4` checkpoint (activations far beyond the fp16x3 range, |x| < 8190) used to fail
+    one call late.  Now the first forward of the handle is checked, the handle is rebuilt in bf16x6 (fp32's range) with a
+    RuntimeWarning, the batch is re-run: finite, oracle-equal waveform from the FIRST call on, `precision_in_use` says so."""
+    def patch(vsd):
+        vsd["conv_pre.bias"] = vsd["conv_pre.bias"] + 3.0e4
+        return vsd
+    pipe, batch, h, vsd = _small_pipeline(tmp_path, patch)
+    gen = pipe.generator
+    with pytest.warns(RuntimeWarning, match="bf16x6"):
+        out = pipe(batch)
+    assert gen.precision_in_use == "bf16x6" and pipe.parrot.precision_in_use == "f16x3"
+    assert bool(torch.isfinite(out["wav"]).all())
+    pipe.check()
+    hop = gen.upsample_factor
+    worst, scale = 0.0, 0.0
+    for b in range(out["ids"].shape[0]):
+        n = int(out["n_samples"][b]) // hop
+        with torch.no_grad():
+            ref = O.code_generator_forward(vsd, h, out["ids"][b:b + 1, :n].cpu(), batch["speaker"][b:b + 1].cpu().reshape(-1, 1))
+        worst = max(worst, float((out["wav"][b:b + 1, :, : n * hop].cpu() - ref).abs().max()))
+        scale = max(scale, float(ref.abs().max()))
+    _report(test="range_fallback_bias_3e4", wav_max_abs_err=worst, ref_max_abs=scale, precision_in_use=gen.precision_in_use)
+    assert worst <= 5e-5, worst
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # later calls: no warning, no rebuild, same result
+        out2 = pipe(batch)
+    assert torch.equal(out2["wav"], out["wav"])
+    # the direct module call takes the same route, and the headroom helper shows why
+    g2 = _gen(h, vsd)
+    with pytest.warns(RuntimeWarning):
+        y = g2(code=out["ids"], spkr=batch["speaker"].reshape(-1, 1), unit_lens=torch.clamp(out["lens"] + 1, max=out["ids"].shape[1]).to(DEV))
+    assert torch.equal(y, out["wav"]) and g2.precision_in_use == "bf16x6"
+    hr = g2.activation_headroom(code=out["ids"], spkr=batch["speaker"].reshape(-1, 1))
+    assert hr["max_abs"]["stage0"] > 8190.0 and hr["headroom"]["stage0"] < 1.0 and hr["max_abs"]["conv_pre"] < 100.0
+    _report(test="activation_headroom_bias_3e4", **{k: float(v) for k, v in hr["max_abs"].items()})
+
+
+def test_activation_headroom_of_the_bench_checkpoint():
+    """The same debug helper on the full-size bench checkpoint: every conv input stays orders of magnitude below 8190."""
+    h = synth.default_voc_config()
+    g = _gen(h, synth.synth_voc_state_dict(h, seed=1234, scale=1.0))
+    b = synth.synth_voc_batch(2, 64, h, seed=0)
+    hr = g.activation_headroom(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV))
+    assert set(hr["max_abs"]) == {"conv_pre", "stage0", "stage1", "stage2", "stage3", "stage4", "conv_post"}
+    assert all(0.0 < v < 100.0 for v in hr["max_abs"].values()), hr
+    _report(test="activation_headroom_bench_checkpoint", **{k: float(v) for k, v in hr["max_abs"].items()})
+    assert g.precision_in_use in (None, "f16x3")  # the helper runs on its own temporary handle
+
+
+def _parrot_full(tmp_path, tsd, cfg, vocab, n_spk, merge=None):
+    cfg = synth.clone_config(cfg)
+    cfg["path"]["root_path"] = str(tmp_path)
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({f"s{i}": i for i in range(n_spk)}, f)
+    m = Parrot(cfg, vocab, 0)
+    m.load_state_dict(tsd)
+    m._merge_override = merge
+    return m.eval().to(DEV)
+
+
+@pytest.mark.parametrize("shape", ["B16xS64xL256", "B4xS375xL1500"])
+def test_merged_vs_unmerged_projections_and_the_deep_tie_guard(tmp_path, shape):
+    """VERDICT r3 item 4.  (i) The host-side fold of the double projections (quirk Q3) against keeping them apart: logit error of
+    both against the fp32 oracle AND an fp64 run of the oracle -- the default is the one closer to fp64.  (ii) The tie guard now
+    re-evaluates conv2 + bias + residual of the last decoder block and the head in fp64 for guarded positions: its logits are
+    compared with the fp64 oracle beside the plain fp32 logits of the same positions."""
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    cfg = synth.default_tte_config()
+    vocab, n_spk = 300, 10
+    B, S = (16, 64) if shape.startswith("B16") else (4, 375)
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=42, forced_duration=4)
+    batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=0)
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    with torch.no_grad():
+        r32 = O.tte_forward(tsd, cfg, batch)
+        r64 = O.tte_forward({k: v.double() for k, v in tsd.items()}, cfg, batch)
+    m = r32["tgt_mask"]
+    row = dict(test="tte_merge_and_deep_guard", shape=shape, positions=int(m.sum()),
+               oracle_fp32_vs_fp64=float((r32["logits"].double() - r64["logits"]).abs().amax(-1)[m].max()))
+    ids_by_mode = {}
+    for name, merge in (("merged", True), ("unmerged", False)):
+        model = _parrot_full(tmp_path, tsd, cfg, vocab, n_spk, merge=merge)
+        logits = model(gb, inference=True)[0].cpu()
+        ids_by_mode[name] = model.infer_dense(gb)["ids"].cpu()
+        row[f"logits_err_vs_oracle_{name}"] = float((logits - r32["logits"]).abs().amax(-1)[m].max())
+        row[f"logits_err_vs_fp64_{name}"] = float((logits.double() - r64["logits"]).abs().amax(-1)[m].max())
+        if merge:  # deep guard statistics on the default handle
+            gs = model.guard_stats()
+            glog, gpos = model.guard_logits()
+            row["n_guarded"] = gs["n_guarded"]
+            if glog.shape[0]:
+                bb, tt = gpos[:, 0].long(), gpos[:, 1].long()
+                ref64 = r64["logits"][bb, tt]                      # (n, V)
+                e_ref = (glog.double() - ref64).abs().amax(-1)    # refined logits vs fp64 oracle
+                e_raw = (logits[bb, tt].double() - ref64).abs().amax(-1)
+                top2 = torch.topk(ref64, 2, dim=-1).values
+                margin64 = top2[:, 0] - top2[:, 1]
+                row.update(guard_refined_err_vs_fp64=float(e_ref.max()), guard_fp32_err_vs_fp64=float(e_raw.max()),
+                           guard_worst_margin64_minus_2err_refined=float((margin64 - 2 * e_ref).min()),
+                           guard_worst_margin64_minus_2err_fp32=float((margin64 - 2 * e_raw).min()))
+                # the refinement removes the last block's accumulation error: never worse than the fp32 logits of those positions
+                assert float(e_ref.max()) <= float(e_raw.max()) + 2e-6, row
+                # ... and its argmax is what the handle returned for them
+                assert torch.equal(torch.argmax(glog, -1), ids_by_mode[name][bb, tt])
+        del model
+    ref_ids = torch.argmax(r32["logits"], -1)
+    row["ids_mismatch_merged"] = int((ids_by_mode["merged"] != ref_ids)[m].sum())
+    row["ids_mismatch_unmerged"] = int((ids_by_mode["unmerged"] != ref_ids)[m].sum())
+    row["default"] = "merged"
+    _report(**row)
+    assert row["logits_err_vs_oracle_merged"] <= 1e-4 and row["logits_err_vs_oracle_unmerged"] <= 1e-4
+    # the default (merged) is not further from fp64 than the unmerged evaluation, beyond run-to-run rounding
+    assert row["logits_err_vs_fp64_merged"] <= row["logits_err_vs_fp64_unmerged"] * 1.25 + 1e-6, row
+    assert row["ids_mismatch_merged"] == 0, row
