@@ -94,6 +94,8 @@ struct ConvParams {
                              // stream) folding makes every accumulation step round at ulp(|res|) instead of ulp(|sum|)
     int lean;                // conv_split_kernel: buffer-addressed prologue / epilogue for plain convs (conv_acc_init_lean)
     int n_cus;           // CUs of the device (workgroup slots per round = n_cus x workgroups per CU)
+    int epi16;           // conv_split16: the output / residual rows are 16-byte aligned (Tout % 4 == 0, aligned bases): the epilogue
+                         // transposes each 16-row tile through a wave-private LDS region and moves 16 bytes per lane and instruction
     float acc_scale;         // split schemes with pre-scaled operands (conv_split.h): the accumulator holds acc_scale * sum
     float out_scale;         // = 1 / acc_scale (both exact powers of two; 1 for every other kernel)
 };
@@ -315,6 +317,13 @@ __device__ __forceinline__ float row_tile_load(const RowTile& t, int voff, int s
 }
 __device__ __forceinline__ void row_tile_store(const RowTile& t, float v, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), t.rsrc, voff, soff, 0);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 row_tile_load4(const RowTile& t, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, voff, soff, 0));
+}
+__device__ __forceinline__ void row_tile_store4(const RowTile& t, const f32x4& v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), t.rsrc, voff, soff, 0);
 }
 // plain convs whose (M, Tout) tile of one batch row fits 31-bit byte offsets (every layer of the path) take the lean code
 __host__ __device__ __forceinline__ bool conv_lean_ok(const ConvParams& p) { return p.lean != 0 && p.u == 1 && (long)p.M * p.Tout * 4 < 0x7fffffffL; }

@@ -105,42 +105,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     f32x4 acc[TM][TN];
     const int m_wave = mblock * BM + wm * TM * 16;
     const int n_wave = t0 + wn * TN * 16;
-    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
-    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
-    const bool fold_res = rb != nullptr && p.act == ACT_NONE && p.fold_res != 0;
-    const int out_row_bytes = p.Tout * 4;
-    int vo[TN];  // byte offset of this lane's (row 4 g4, column) inside the tile rows; 0x80000000: column out of range
+    // accumulators start at bias * scale; the residual is added in the epilogue, after the sum, as the reference does
+    // (xt = c2(xt); x = xt + x, models.py:37-38) -- for every tile shape and alignment alike
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n_wave + tn * 16 + l15;
-        vo[tn] = (n < p.Ncols) ? (4 * g4 * p.Tout + n) * 4 : (int)0x80000000;
-    }
-    {
-        const RowTile rt = row_tile(fold_res ? rb : p.x, p.M, p.Tout);  // (never read when !fold_res)
+    for (int tm = 0; tm < TM; ++tm) {
+        float bs[4];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int m0 = m_wave + tm * 16;  // wave-uniform
-            if (fold_res) {  // (the residual loads go out first: the longest latency of the prologue)
+        for (int r = 0; r < 4; ++r) bs[r] = p.bias ? p.bias[min(m_wave + tm * 16 + 4 * g4 + r, p.M - 1)] * p.acc_scale : 0.f;
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tm][tn][r] = row_tile_load(rt, vo[tn], (m0 + r) * out_row_bytes);
-            }
-            float bs[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bs[r] = p.bias ? p.bias[min(m0 + 4 * g4 + r, p.M - 1)] * p.acc_scale : 0.f;
-            if (fold_res) {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tm][tn][r] = fmaf(acc[tm][tn][r], p.acc_scale, bs[r]);  // = (res + bias) * scale
-            } else {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tm][tn][r] = bs[r];
-            }
-        }
+            for (int r = 0; r < 4; ++r) acc[tm][tn][r] = bs[r];
     }
 
     // ---- weight stream ---------------------------------------------------------------------------------------------
@@ -227,13 +202,75 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
         __syncthreads();
     }
 
-    // ---- epilogue (plain convs only): scale back, late residual / activation / MRF accumulation modes ------------------
-    // v = y_old + (max(acc * out_scale, relu ? 0 : -inf) + res): the same operations in the same order as conv_epilogue
-    const bool late_res = rb != nullptr && !fold_res;
+    // ---- epilogue (plain convs only): scale back, activation, residual, MRF accumulation modes ----------------------------
+    // v = y_old + (max(acc * out_scale, relu ? 0 : -inf) + res)
+    float* __restrict__ yb = p.y + (size_t)b * p.y_bstride;
+    const float* __restrict__ rb = p.res ? p.res + (size_t)b * p.res_bstride : nullptr;
+    const int out_row_bytes = p.Tout * 4;
+    const bool late_res = rb != nullptr;
     const bool has_acc = p.epi != EPI_STORE;
     const bool do_div = p.epi == EPI_ADD_DIV;
     const bool relu = p.act == ACT_RELU;
     const RowTile yt = row_tile(yb, p.M, p.Tout), rt = row_tile(late_res ? rb : yb, p.M, p.Tout);
+    if (p.epi16) {
+        // 16-byte epilogue: the C/D layout gives a lane ONE column of four rows, i.e. four 4-byte accesses to four different rows
+        // per tile (64-80 stores, and as many loads per residual / accumulate operand, per lane: ~100 clocks of issue each beside
+        // another workgroup's MFMAs).  Each 16-row tile of the wave goes through a wave-private LDS region instead
+        // ([16 rows][TN * 16 + 4 floats]: the slab buffers are dead after the last chunk's barrier, no further barrier needed: one
+        // wave's DS instructions execute in order) and leaves as row segments: lane -> 4 consecutive columns of one row, a wave
+        // instruction -> 3-4 contiguous 256- / 320-byte runs.  Same values, same arithmetic per element.
+        constexpr int RS = TN * 16 + 4, GPR = TN * 4;  // staged row stride (floats; 4 RS = 16 mod 32: 2-way write conflicts only), 16-byte groups per row
+        float* stg = reinterpret_cast<float*>(smem_raw) + wave * (16 * RS);
+        int vq[TN], lq[TN];
+#pragma unroll
+        for (int q = 0; q < TN; ++q) {
+            const int g = lane + 64 * q, row = g / GPR, cg = g - row * GPR;
+            const int n = n_wave + cg * 4;
+            vq[q] = (n < p.Ncols) ? (row * p.Tout + n) * 4 : (int)0x80000000;
+            lq[q] = row * RS + cg * 4;
+        }
+        const int wbase = 4 * g4 * RS + l15;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int m0 = m_wave + tm * 16;
+            const int soff = m0 * out_row_bytes;
+            f32x4 rv[TN], yv[TN];
+            if (late_res) {
+#pragma unroll
+                for (int q = 0; q < TN; ++q) rv[q] = row_tile_load4(rt, vq[q], soff);
+            }
+            if (has_acc) {
+#pragma unroll
+                for (int q = 0; q < TN; ++q) yv[q] = row_tile_load4(yt, vq[q], soff);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[tm][tn][r] * p.out_scale;
+                    if (relu) v = fmaxf(v, 0.f);
+                    stg[wbase + r * RS + tn * 16] = v;
+                }
+#pragma unroll
+            for (int q = 0; q < TN; ++q) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(stg + lq[q]);
+                if (late_res) v = v + rv[q];
+                if (has_acc) {
+                    v = yv[q] + v;
+                    if (do_div) v = v / p.div;
+                }
+                row_tile_store4(yt, v, vq[q], soff);
+            }
+        }
+        return;
+    }
+    // rows that do not start on 16-byte boundaries (odd lengths): 4-byte accesses in the C/D layout, the same arithmetic
+    int vo[TN];  // byte offset of this lane's (row 4 g4, column) inside the tile rows; 0x80000000: column out of range
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n_wave + tn * 16 + l15;
+        vo[tn] = (n < p.Ncols) ? (4 * g4 * p.Tout + n) * 4 : (int)0x80000000;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int m0 = m_wave + tm * 16;
@@ -286,7 +323,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
 template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
 inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16, COLS = (BN + CONV_HALO + 63) / 64 * 64;
-    const size_t lds = (size_t)2 * SCH::NP * 4 * COLS * 16;
+    // slab double buffer, or the epilogue's wave-private staging rows ([16][TN * 16 + 4] floats per wave) where that is larger
+    const size_t lds = std::max((size_t)2 * SCH::NP * 4 * COLS * 16, (size_t)WAVES_M * WAVES_N * 16 * (TN * 16 + 4) * sizeof(float));
     auto kern = conv_split16_kernel<SCH, WAVES_M, WAVES_N, TM, TN, K, MINW>;
     static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
     {

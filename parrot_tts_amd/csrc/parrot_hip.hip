@@ -540,6 +540,11 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         split16_tile(variant16, t.bm, t.bn, c->kk);
         // conv_split16_kernel addresses the (M, Tout) output / residual tile of a batch row with 32-bit byte offsets (RowTile)
         if ((double)c->M * Tout * 4.0 >= 2147483648.0) return fail(PARROT_E_UNSUPPORTED, "conv_run: output row tile larger than 2 GiB");
+        {   // rows that start on 16-byte boundaries take the 16-byte epilogue (PARROT_EPI16=0: A/B switch of the round-4 change)
+            static const int epi16 = [] { const char* e = getenv("PARROT_EPI16"); return e ? atoi(e) : 1; }();
+            auto al16 = [](const void* q, long stride) { return (reinterpret_cast<size_t>(q) & 15) == 0 && (stride & 3) == 0; };
+            p.epi16 = epi16 && (Tout % 4 == 0) && al16(y, p.y_bstride) && (!res || al16(res, p.res_bstride));
+        }
     } else if (c->prec >= 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
         // better (76 vs 61 TF on the qkv projection); every other layer is faster on the 64x64 wave tile

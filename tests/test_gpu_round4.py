@@ -126,15 +126,22 @@ def test_range_safe_fallback_rebuilds_in_bf16x6_and_matches_the_oracle(tmp_path)
     assert bool(torch.isfinite(out["wav"]).all())
     pipe.check()
     hop = gen.upsample_factor
-    worst, scale = 0.0, 0.0
+    # activations of 3e4 put one fp32 ulp at 2e-3: the yardstick is the reference's own fp32 distance to an fp64 run of itself
+    # (as for the "hot" golden), not the 5e-5 of well-scaled checkpoints
+    worst, own, scale = 0.0, 0.0, 0.0
+    vsd64 = {k: v.double() for k, v in vsd.items()}
     for b in range(out["ids"].shape[0]):
         n = int(out["n_samples"][b]) // hop
+        ids_b, spk_b = out["ids"][b:b + 1, :n].cpu(), batch["speaker"][b:b + 1].cpu().reshape(-1, 1)
         with torch.no_grad():
-            ref = O.code_generator_forward(vsd, h, out["ids"][b:b + 1, :n].cpu(), batch["speaker"][b:b + 1].cpu().reshape(-1, 1))
-        worst = max(worst, float((out["wav"][b:b + 1, :, : n * hop].cpu() - ref).abs().max()))
+            ref = O.code_generator_forward(vsd, h, ids_b, spk_b)
+            ref64 = O.code_generator_forward(vsd64, h, ids_b, spk_b)
+        worst = max(worst, float((out["wav"][b:b + 1, :, : n * hop].cpu().double() - ref64).abs().max()))
+        own = max(own, float((ref.double() - ref64).abs().max()))
         scale = max(scale, float(ref.abs().max()))
-    _report(test="range_fallback_bias_3e4", wav_max_abs_err=worst, ref_max_abs=scale, precision_in_use=gen.precision_in_use)
-    assert worst <= 5e-5, worst
+    _report(test="range_fallback_bias_3e4", wav_err_vs_fp64=worst, reference_fp32_err_vs_fp64=own, ref_max_abs=scale,
+            precision_in_use=gen.precision_in_use)
+    assert worst <= 3.0 * own + 5e-5, (worst, own)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")  # later calls: no warning, no rebuild, same result
