@@ -88,10 +88,13 @@ struct SchF16x3 {
     static constexpr int last_a(int pc) { return pc == 1 ? 0 : 2; }
     static __device__ __forceinline__ void split(float x0, float x1, unsigned (&q)[2]) {
         const f32x2 v = {x0, x1};
-        const f16x2 h = __builtin_convertvector(v, f16x2);
-        const f32x2 r = v - __builtin_convertvector(h, f32x2);  // exact
-        q[0] = __builtin_bit_cast(unsigned, h);
-        q[1] = pk_f16(r[0], r[1]);
+        q[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+        // r = x - float(hi), exact: one v_fma_mix_f32 per element (fp16 source read straight out of the packed pair) instead of
+        // v_cvt_f32_f16 + half a v_pk_add_f32 -- hipcc folds fma(hi, -1, x) back into the subtraction, hence the asm
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(q[0]), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(q[0]), "v"(x1));
+        q[1] = pk_f16(r0, r1);
     }
 };
 struct SchBf16 {

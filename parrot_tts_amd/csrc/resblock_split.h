@@ -125,12 +125,7 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
                     for (int e = 0; e < 2; ++e) {
                         const f32x2 vv = {v[nt][8 * q + 4 * g + 2 * e], v[nt][8 * q + 4 * g + 2 * e + 1]};
                         const f32x2 a = (SCH::XS != 1.f) ? vv * mul : vv, bq = vv * m2;  // lrelu(c v) = max(c v, c slope v): packed multiplies
-                        float v0 = max_nc(a[0], bq[0]), v1 = max_nc(a[1], bq[1]);
-                        if (edge) {
-                            v0 = tok[nt] ? v0 : 0.f;
-                            v1 = tok[nt] ? v1 : 0.f;
-                        }
-                        SCH::split(v0, v1, qq[g][e]);
+                        SCH::split(max_nc(a[0], bq[0]), max_nc(a[1], bq[1]), qq[g][e]);
                     }
                 // A lane holds 4 of the 8 channels of both octets of this column (the other 4 sit in lane ^ 32).  Swap the
                 // halves across the two half-waves (v_permlane32_swap): lane (col, half h) then owns octet h completely and
@@ -143,6 +138,20 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
                     *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES) = uint4{r0[0], r1[0], r0[1], r1[1]};
                 }
             }
+        }
+        // Positions outside the true sequence are zero INPUTS of every conv (the reference's per-layer zero padding).  Only the
+        // windows that touch a sequence end (`edge`, wave-uniform) pay for it: the lane overwrites the slots of its out-of-sequence
+        // columns with zeros -- interior windows (the bulk) carry no per-element mask instructions (2 of 7 VALU per element before).
+        if (edge) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                if (!tok[nt]) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int pc = 0; pc < NPC; ++pc)
+                            *reinterpret_cast<uint4*>(smem_raw + (2 * wm + q) * CH_BYTES + half * OCT_BYTES + col[nt] * 16 + pc * PIECE_BYTES) = uint4{0u, 0u, 0u, 0u};
+                }
         }
     };
 
@@ -165,21 +174,15 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
         load_a_piece(A[1], pc, gbase + K);  // (tap 0, chunk 1)
     }
 
-    if (edge) {
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) R[nt][r] = tok[nt] ? R[nt][r] : 0.f;  // (already 0 from the range check; keeps the invariant explicit)
-    }
-    write_p(R, SCH::XS);
+    write_p(R, SCH::XS);  // (out-of-sequence columns of R are 0 from the range-checked loads)
     __syncthreads();
 
     const int center = (K - 1) / 2;
     auto load_b = [&](s16x8 (&bb)[NTW][NPC], int ch, int shift) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const int cc = min(max(col[nt] + shift, 0), W - 1);  // clamped: only garbage columns ever read a clamped one
-            const char* src = smem_raw + ch * CH_BYTES + half * OCT_BYTES + cc * 16;
+            // (unclamped: columns outside [0, W) are read only for output columns that are invalid anyway; LDS never faults)
+            const char* src = smem_raw + ch * CH_BYTES + half * OCT_BYTES + (col[nt] + shift) * 16;
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) bb[nt][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
@@ -262,10 +265,9 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = (SCH::XS != 1.f) ? acc[nt][r] * i2 : acc[nt][r];
-                R[nt][r] = (!edge || tok[nt]) ? v : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) R[nt][r] = (SCH::XS != 1.f) ? acc[nt][r] * i2 : acc[nt][r];
+        // (columns outside the sequence now hold garbage in R: they never feed a valid column -- write_p zeroes their operand slots --
+        //  and the final store drops them or leaves them in the row's unspecified tail)
         if (m + 2 < p.n_conv) {
             __syncthreads();
             write_p(R, SCH::XS);
@@ -274,7 +276,11 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
     }
 
     // ---- write the central TT columns (registers -> global, 128-byte runs per row) ---------------------------------
-    float* __restrict__ yb = p.y + (size_t)b * C * p.T + (size_t)(32 * wm) * p.T;
+    // buffer-addressed like the layer kernels' RowTile (conv_mfma.h): ONE lane-dependent offset per column tile (0x80000000 for a
+    // column outside the window's own output range: loads return 0, stores are dropped), scalar row offsets -- the 64-bit pointer
+    // arithmetic and per-element selects of the first version were ~600 VALU instructions per window, two conversion passes' worth
+    const RowTile yt = row_tile(p.y + (size_t)b * C * p.T, C, p.T);
+    const int row_bytes = p.T * 4;
     const bool has_acc = p.epi != EPI_STORE;
     const bool do_div = p.epi == EPI_ADD_DIV;
 #pragma unroll
@@ -282,19 +288,24 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
         const int c = col[nt] - p.H;
         const int t = tile * p.TT + c;
         const bool ok = c >= 0 && c < p.TT && t < p.T;
-        float yv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yv[r] = 0.f;
+        const int voff = ok ? (4 * half * p.T + t) * 4 : (int)0x80000000;
+        float v[16];
         if (has_acc) {
+            float yv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yv[r] = yb[ok ? (size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t : 0];
+            for (int r = 0; r < 16; ++r) yv[r] = row_tile_load(yt, voff, (32 * wm + (r & 3) + 8 * (r >> 2)) * row_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = yv[r] + R[nt][r];
+            if (do_div) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] / p.div;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.f + R[nt][r];  // (as the accumulating form with y = 0: -0 comes out as +0 in both)
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = yv[r] + R[nt][r];
-            if (do_div) v = v / p.div;
-            if (ok) yb[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.T + t] = v;
-        }
+        for (int r = 0; r < 16; ++r) row_tile_store(yt, v[r], voff, (32 * wm + (r & 3) + 8 * (r >> 2)) * row_bytes);
     }
 }
 
@@ -357,19 +368,11 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
             unsigned qq[2][2][NPC];           // [tile of the pair][pair e][piece]
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int c = col0 + (np + u) * 16;
-                const int t = t_base + c;
-                const bool tk = t >= 0 && t < Tlim;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const f32x2 vv = {v[np + u][2 * e], v[np + u][2 * e + 1]};
                     const f32x2 a = (SCH::XS != 1.f) ? vv * mul : vv, bq = vv * m2;
-                    float v0 = max_nc(a[0], bq[0]), v1 = max_nc(a[1], bq[1]);
-                    if (edge) {
-                        v0 = tk ? v0 : 0.f;
-                        v1 = tk ? v1 : 0.f;
-                    }
-                    SCH::split(v0, v1, qq[u][e]);
+                    SCH::split(max_nc(a[0], bq[0]), max_nc(a[1], bq[1]), qq[u][e]);
                 }
             }
             // a lane holds 4 of the 8 channels of an octet (the other 4 sit in lane ^ 16): v_permlane16_swap gives the even
@@ -381,6 +384,18 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
                 const auto r0 = __builtin_amdgcn_permlane16_swap(qq[0][0][pc], qq[1][0][pc], false, false);
                 const auto r1 = __builtin_amdgcn_permlane16_swap(qq[0][1][pc], qq[1][1][pc], false, false);
                 *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES) = uint4{r0[0], r1[0], r0[1], r1[1]};
+            }
+        }
+        if (edge) {  // windows at a sequence end only: zero the operand slots of out-of-sequence columns (see resblock_split_kernel)
+#pragma unroll
+            for (int np = 0; np < NT; np += 2) {
+                const int c = col0 + (np + (g4 & 1)) * 16;  // the column whose octet this lane stored above
+                const int t = t_base + c;
+                if (!(t >= 0 && t < Tlim)) {
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc)
+                        *reinterpret_cast<uint4*>(smem_raw + (g4 >> 1) * OCT_BYTES + c * 16 + pc * PIECE_BYTES) = uint4{0u, 0u, 0u, 0u};
+                }
             }
         }
     };
@@ -408,8 +423,10 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
     auto load_b = [&](s16x8 (&bb)[2][NPC], int pr, int shift) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int cc = min(max(col0 + (2 * pr + q) * 16 + shift, 0), W - 1);
-            const char* src = smem_raw + (g4 & 1) * OCT_BYTES + cc * 16;
+            // (no clamp: a column outside [0, W) is only ever read for output columns within the conv's reach of the window edge,
+            //  which are invalid by construction; the address stays inside this piece's neighbours or out of the allocation, where
+            //  LDS reads return 0 -- garbage either way, never a fault.  The clamp was 2 VALU per fragment read: 85 of 183 per step pair)
+            const char* src = smem_raw + (g4 & 1) * OCT_BYTES + (col0 + (2 * pr + q) * 16 + shift) * 16;
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) bb[q][pc] = *reinterpret_cast<const s16x8*>(src + pc * PIECE_BYTES);
         }
@@ -481,12 +498,9 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
         conv(p.dil[m + 1]);
         const float i2 = 1.f / s2;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int t = t_base + col0 + nt * 16;
-            const bool tk = !edge || (t >= 0 && t < Tlim);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R[nt][r] = tk ? ((SCH::XS != 1.f) ? fmaf(acc[nt][r], i2, R[nt][r]) : acc[nt][r] + R[nt][r]) : 0.f;
-        }
+            for (int r = 0; r < 4; ++r) R[nt][r] = (SCH::XS != 1.f) ? fmaf(acc[nt][r], i2, R[nt][r]) : acc[nt][r] + R[nt][r];
         if (m + 2 < p.n_conv) {
             __syncthreads();
             write_p(R, SCH::XS);
@@ -494,24 +508,40 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
         }
     }
 
-    float* __restrict__ yb = p.y + (size_t)b * C * p.T;
+    const RowTile yt = row_tile(p.y + (size_t)b * C * p.T, C, p.T);  // buffer-addressed (see resblock_split_kernel)
+    const int row_bytes = p.T * 4;
     const bool has_acc = p.epi != EPI_STORE;
     const bool do_div = p.epi == EPI_ADD_DIV;
+    if (has_acc) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int c = col0 + nt * 16 - p.H;
-        const int t = tile * p.TT + c;
-        const bool ok = c >= 0 && c < p.TT && t < p.T;
-        float yv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (has_acc) {
+        for (int n0 = 0; n0 < NT; n0 += 4) {  // four column tiles per batch: 16 loads in flight
+            float yv[4][4];
+            int voff[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yv[r] = yb[ok ? (size_t)(4 * g4 + r) * p.T + t : 0];
+            for (int i = 0; i < 4; ++i) {
+                const int c = col0 + (n0 + i) * 16 - p.H;
+                const int t = tile * p.TT + c;
+                voff[i] = (c >= 0 && c < p.TT && t < p.T) ? (4 * g4 * p.T + t) * 4 : (int)0x80000000;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[i][r] = row_tile_load(yt, voff[i], r * row_bytes);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = yv[i][r] + R[n0 + i][r];
+                    if (do_div) v = v / p.div;
+                    row_tile_store(yt, v, voff[i], r * row_bytes);
+                }
         }
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = yv[r] + R[nt][r];
-            if (do_div) v = v / p.div;
-            if (ok) yb[(size_t)(4 * g4 + r) * p.T + t] = v;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = col0 + nt * 16 - p.H;
+            const int t = tile * p.TT + c;
+            const int voff = (c >= 0 && c < p.TT && t < p.T) ? (4 * g4 * p.T + t) * 4 : (int)0x80000000;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) row_tile_store(yt, 0.f + R[nt][r], voff, r * row_bytes);
         }
     }
 }
