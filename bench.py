@@ -247,6 +247,10 @@ def main():
         wav = out if out is not None else wav
         fence()
         elapsed = time.perf_counter() - t0
+        # a run that fell back to another precision (range-safe fallback of the shims) is not the run that was asked for
+        in_use = {"tte": parrot.precision_in_use if workload == "full" else precision, "vocoder": gen.precision_in_use}
+        if any(v not in (None, precision) for v in in_use.values()):
+            raise SystemExit(f"bench.py: asked for precision {precision} but the handles ran as {in_use} (non-finite output -> fallback)")
         names = tile_names(precision)
         prof = (C.c_double * (4 * len(names)))()
         _lib.check(lib.parrot_prof_end(prof, len(names)))

@@ -434,7 +434,11 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
     // one conv: loop over step pairs (weight set 0 / 1), six tile pairs per step alternating the operand sets
     auto conv = [&](int dil) __attribute__((always_inline)) {
         const int tpd = (g4 >> 1) * dil - center * dil;  // this lane's tap-parity shift, centred
-        load_b(Bv[0], 0, tpd);
+        // An odd tap count is padded with ONE zero-weight tap (index K, the odd-parity lanes of the last step).  Its operand must be
+        // finite -- 0 x inf = NaN -- and, with unclamped reads, columns beyond the conv's true reach may hold anything: those lanes
+        // re-read tap K - 1 (inside the reach, finite wherever the output column is valid) instead of stepping one tap further out.
+        const int tpd_last = tpd - (((K & 1) && (g4 >> 1)) ? dil : 0);
+        load_b(Bv[0], 0, S == 1 ? tpd_last : tpd);
         for (int s2 = 0; s2 < S; s2 += 2) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -442,8 +446,8 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
 #pragma unroll
                 for (int pr = 0; pr < NP; ++pr) {
                     const int cur = pr & 1;  // NP is even: every step starts on operand set 0
-                    if (pr + 1 < NP) load_b(Bv[cur ^ 1], pr + 1, tpd + 2 * s * dil);
-                    else load_b(Bv[cur ^ 1], 0, tpd + 2 * (s + 1) * dil);  // (after the last step: discarded)
+                    if (pr + 1 < NP) load_b(Bv[cur ^ 1], pr + 1, (s == S - 1 ? tpd_last : tpd) + 2 * s * dil);
+                    else load_b(Bv[cur ^ 1], 0, (s + 1 == S - 1 ? tpd_last : tpd) + 2 * (s + 1) * dil);  // (after the last step: discarded)
 #pragma unroll
                     for (int t = 0; t < NTERM; ++t) {
 #pragma unroll
