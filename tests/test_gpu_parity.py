@@ -511,12 +511,17 @@ def test_tte_flags_non_finite_logits(tmp_path):
     sd["decoder_layers.0.convlayer.conv1.bias"] = sd["decoder_layers.0.convlayer.conv1.bias"] + 5.0e4
     model = _parrot(cfg, 30, 1, sd, tmp_path)
     batch = {k: v.to(DEV) for k, v in synth.synth_tte_batch(2, 9, 30, 1, seed=1).items()}
+    model.range_fallback = False  # (the fail-loud contract; by default the first decode falls back to bf16x6, checked below)
     with pytest.raises(FloatingPointError):
         model.infer(batch)
+    m1 = _parrot(cfg, 30, 1, sd, tmp_path)
+    with pytest.warns(RuntimeWarning, match="bf16x6"):
+        rows = m1.infer(batch)  # range-safe fallback: the handle is rebuilt in bf16x6 and the batch re-run
+    assert len(rows) == 2 and m1.precision_in_use == "bf16x6"
     ops.set_default_precision(ops.PREC_BF16X6)
     try:
         m2 = _parrot(cfg, 30, 1, sd, tmp_path)
-        assert len(m2.infer(batch)) == 2
+        assert m2.infer(batch) == rows
     finally:
         ops.set_default_precision(ops.PREC_DEFAULT)
 
