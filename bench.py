@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("PARROT_BENCH_OVERLAP", "0")),
                     help="1: the headline run itself uses the two-stage pipeline across steps (TTE of batch i on a side stream beside "
                          "the vocoder of batch i-1); default 0: one batch at a time, the pipelined rate is reported next to it")
+    ap.add_argument("--row-groups", type=int, default=None,
+                    help="row groups of the in-batch software pipeline (decoder of group g + 1 beside the vocoder of group g); "
+                         "default: SynthesisPipeline's (2, PARROT_ROW_GROUPS); 1 = the whole batch through one stage after the other")
     ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "bf16", "f16"], default=os.environ.get("PARROT_BENCH_PRECISION", "f16x3"),
                     help="product evaluation of the conv kernels for layers with >= 16 channels (fp32 data either way): f16x3 (default), "
                          "bf16x6 and f32 are parity-grade; bf16 / f16 are the single-MFMA reduced-precision operating point")
@@ -202,7 +205,8 @@ def main():
         workload = workload or a.workload
         ops.set_default_precision(ops.PREC_NAMES[precision])
         cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
-        pipe = SynthesisPipeline(parrot, gen)
+        pipe = SynthesisPipeline(parrot, gen, row_groups=(None if a.row_groups is None else a.row_groups))
+        run.row_groups = [n for _, n in pipe._groups(B)]
         batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(B, S, vocab, n_spk, seed=rank).items()}
         vb = {k: v.to(dev) for k, v in synth.synth_voc_batch(B, 4 * S, h, seed=rank).items()}
 
@@ -358,6 +362,7 @@ def main():
         return out
 
     elapsed, rows, n_samples_step, pieces = run(a.precision, a.steps, a.warmup, overlap_steps=bool(a.overlap))
+    head_groups = list(run.row_groups)
     gather_ms = run.gather_ms
 
     if rank == 0:
@@ -419,6 +424,11 @@ def main():
         res["schedule"] = ("two-stage pipeline across steps: the TTE of batch i runs on a side HIP stream beside the vocoder of batch "
                            "i-1 (SynthesisPipeline.submit); every batch submitted inside the timed region is finished inside it"
                            if (a.overlap and a.workload == "full") else "one batch at a time")
+        if a.workload == "full" and not a.overlap and len(head_groups) > 1:
+            res["schedule"] += ("; inside a batch the TTE decoder of row group g + 1 runs on a side HIP stream beside the vocoder of row "
+                                "group g (groups of %s rows; encoder, durations and the expanded length are the whole batch's, "
+                                "results identical to the ungrouped run)" % "+".join(str(n) for n in head_groups))
+        res["config"]["row_groups"] = head_groups if a.workload == "full" else [B]
     if world == 1 and a.workload == "full" and not a.no_alt:
         # the same steps under the other schedule, for reference (kernel timings of the pipelined schedule include the
         # side stream's interference, so `roofline` is only clean with one batch at a time: the default headline)

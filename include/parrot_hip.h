@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PARROT_ABI_VERSION 4
+#define PARROT_ABI_VERSION 5
 
 enum {
     PARROT_OK = 0,
@@ -267,6 +267,15 @@ int parrot_tte_encode(parrot_tte_t*, const int64_t* phones, const uint8_t* src_m
 int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L,
                       int64_t* ids, uint8_t* tgt_mask, float* logits /* nullable */,
                       void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
+/* Phase 2 for rows [row0, row0 + n_rows) of the encoded batch only (B = the batch `state` was encoded with; L = the WHOLE
+ * batch's max(out_lens): pe[L] is indexed by the batch-max length whichever rows run, parrot.py:106).  ids / tgt_mask / logits
+ * point at the group's own first row ((n_rows, L) ...), ws needs workspace_bytes(n_rows, S, L).  Every decoder kernel works row by
+ * row, so a row decoded in a group equals the same row of parrot_tte_decode bit for bit; a caller can hand the first rows to the
+ * vocoder while the next group is still decoding on another stream (SynthesisPipeline row groups).  Groups of one batch run in
+ * row order on ONE stream: the group with row0 = 0 restarts the tie-guard statistics, later groups add to them. */
+int parrot_tte_decode_rows(parrot_tte_t*, int32_t B, int32_t S, int32_t L, int32_t row0, int32_t n_rows,
+                           int64_t* ids, uint8_t* tgt_mask, float* logits /* nullable */,
+                           void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
 /* Device-side flags.  Synchronises `stream`, clears the flag; returns 0, PARROT_E_RANGE (a bad phone / speaker id <-> the
  * reference's Embedding IndexError) or PARROT_E_NONFINITE (NaN / inf logits at some position of the last decode: an
  * activation beyond the fp16 split scheme's range -- the ids of that call are not to be trusted). */

@@ -104,6 +104,7 @@ SIGNATURES = {
     "parrot_tte_workspace_bytes": (sz, [vp, i32, i32, i32]),
     "parrot_tte_encode": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_decode": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
+    "parrot_tte_decode_rows": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_check": (C.c_int, [vp, vp]),
     "parrot_tte_status_async": (C.c_int, [vp, vp, vp]),
     "parrot_tte_status_peek_async": (C.c_int, [vp, vp, vp]),
@@ -131,7 +132,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.parrot_abi_version() != 4:
+        if handle.parrot_abi_version() != 5:
             raise ImportError("libparrot_hip.so ABI version mismatch")
         _lib = handle
     return _lib

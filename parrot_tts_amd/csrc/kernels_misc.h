@@ -282,6 +282,8 @@ static __global__ __launch_bounds__(256) void dur_prefix_kernel(const int64_t* _
     }
 }
 
+constexpr int TIE_GUARD_MAX = 256;  // guarded positions per batch (argmax_cf_kernel / tie_guard_refine_kernel below)
+
 // ---------------------------------------------------------------------------------------------
 // Length regulator + positional row (duration.py:6-24, parrot.py:106, data.py:8-20):
 // y[b, c, t] = (t < len_b ? enc[b, c, src(t)] : 0) + pe[L][c], src(t) = first s with cum[b,s] > t;
@@ -291,12 +293,16 @@ static __global__ __launch_bounds__(256) void dur_prefix_kernel(const int64_t* _
 static __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ enc, const int32_t* __restrict__ cum,
                                                               const int32_t* __restrict__ out_len, const float* __restrict__ pe_row,
                                                               float* __restrict__ y, uint8_t* __restrict__ tgt_mask, int S, int L, int D,
-                                                              int* __restrict__ gstat = nullptr) {
+                                                              int* __restrict__ gstat = nullptr, int gstat_reset = 1) {
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6;  // lane = frame, the four waves split the channels
     const int t = blockIdx.x * 64 + (threadIdx.x & 63);
-    // (first kernel of a decode: restart the tie-guard statistics {count, ids changed, min margin bits = +inf} of argmax_cf_kernel)
-    if (gstat && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) gstat[threadIdx.x] = threadIdx.x == 2 ? 0x7f800000 : 0;
+    // (first kernel of a decode: restart the tie-guard statistics {count, ids changed, min margin bits = +inf, first list entry of
+    //  this row group} of argmax_cf_kernel; a later row group of the same batch keeps them and notes where its entries start)
+    if (gstat && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) {
+        if (gstat_reset) gstat[threadIdx.x] = threadIdx.x == 2 ? 0x7f800000 : 0;
+        else if (threadIdx.x == 3) gstat[3] = min(gstat[0], TIE_GUARD_MAX);
+    }
     if (t >= L) return;
     const int len = out_len[b];
     if (wave == 0) tgt_mask[(size_t)b * L + t] = (t <= len) ? 1 : 0;
@@ -323,11 +329,10 @@ static __global__ __launch_bounds__(256) void length_regulate_kernel(const float
 // margin; positions whose margin is below `guard` are appended to `glist` ((b, t) pairs, at most TIE_GUARD_MAX) and counted in
 // gstat[0], the smallest margin of the call lands in gstat[2] (float bits; positive floats order like ints) --
 // tie_guard_refine_kernel then re-evaluates the head for exactly those positions in fp64.
-constexpr int TIE_GUARD_MAX = 256;
 constexpr int ARGMAX_WAVES = 16;  // waves per 64 positions: 62-63 codes each at V = 1000 (sixteen loads in flight per position)
 static __global__ __launch_bounds__(64 * ARGMAX_WAVES) void argmax_cf_kernel(const float* __restrict__ logits, int64_t* __restrict__ ids, int V, int L,
                                                                int* __restrict__ err, float guard, int* __restrict__ glist,
-                                                               int* __restrict__ gstat) {
+                                                               int* __restrict__ gstat, int row0 = 0) {
     // lane = time step; the waves scan a slice of the vocabulary each, then the first maximum wins
     // (strict > inside a range, lower range first on ties: torch.argmax's first-occurrence rule)
     __shared__ float bv[ARGMAX_WAVES][64], sv[ARGMAX_WAVES][64];
@@ -377,7 +382,7 @@ static __global__ __launch_bounds__(64 * ARGMAX_WAVES) void argmax_cf_kernel(con
             if (margin >= 0.f) atomicMin(gstat + 2, __float_as_int(margin));
             if (margin < guard) {
                 const int slot = atomicAdd(gstat, 1);
-                if (slot < TIE_GUARD_MAX) { glist[2 * slot] = b; glist[2 * slot + 1] = t; }
+                if (slot < TIE_GUARD_MAX) { glist[2 * slot] = row0 + b; glist[2 * slot + 1] = t; }  // (batch row; b is the row inside this group)
             }
         }
     }
@@ -395,13 +400,14 @@ static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const floa
                                                                       int L, const int* __restrict__ glist, int* __restrict__ gstat,
                                                                       const float* __restrict__ f, const float* __restrict__ h,
                                                                       const float* __restrict__ w2t, const float* __restrict__ b2, int F,
-                                                                      float* __restrict__ gref) {
-    const int n = min(gstat[0], TIE_GUARD_MAX);
-    if ((int)blockIdx.x >= n) return;
+                                                                      float* __restrict__ gref, int row0 = 0) {
+    // this row group's entries are [gstat[3], gstat[0]) of the list; x / f / h / ids are the group's own buffers (row b - row0)
+    const int n = min(gstat[0], TIE_GUARD_MAX), entry = gstat[3] + (int)blockIdx.x;
+    if (entry >= n) return;
     extern __shared__ double xs[];  // D activations of the position (+ F intermediates in the deep form)
     __shared__ double rv[256];
     __shared__ int ri[256];
-    const int b = glist[2 * blockIdx.x], t = glist[2 * blockIdx.x + 1];
+    const int b = glist[2 * entry] - row0, t = glist[2 * entry + 1];
     if (f) {
         double* fs = xs + D;
         for (int j = threadIdx.x; j < F; j += 256) fs[j] = (double)f[((size_t)b * F + j) * L + t];
@@ -438,7 +444,7 @@ static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const floa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double a = acc[q] + (hb ? (double)hb[vv[q]] : 0.0);
-            if (ok[q] && gref) gref[(size_t)blockIdx.x * V + vv[q]] = (float)a;
+            if (ok[q] && gref) gref[(size_t)entry * V + vv[q]] = (float)a;
             if (ok[q] && a > best) { best = a; bi = vv[q]; }  // (codes ascending per thread: the first maximum is kept)
         }
     }

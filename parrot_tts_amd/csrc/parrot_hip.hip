@@ -1584,25 +1584,31 @@ extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const u
     return PARROT_OK;
 }
 
-extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int64_t* ids, uint8_t* tgt_mask, float* logits,
-                                 void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+// Decode rows [row0, row0 + n) of the batch that parrot_tte_encode left in `state` (B rows).  ids / tgt_mask / logits point at the
+// group's own first row.  L is the WHOLE batch's expanded length (pe[L], parrot.py:106) whichever rows are decoded, and every
+// kernel of the decoder works row by row, so a row decoded in a group equals the same row decoded with the whole batch bit for bit.
+static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L, int32_t row0, int32_t B, int64_t* ids, uint8_t* tgt_mask,
+                           float* logits, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
     if (!t || !ids || !tgt_mask || !state || !ws) return fail(PARROT_E_INVALID, "tte_decode: null argument");
-    if (B <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_decode: empty batch");
+    if (Bfull <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_decode: empty batch");
+    if (row0 < 0 || B <= 0 || row0 + B > Bfull) return fail(PARROT_E_INVALID, "tte_decode: row group outside the encoded batch");
     if (L <= 0) return fail(PARROT_E_INVALID, "tte_decode: L must be > 0 (all durations zero: the reference fails in MultiheadAttention too)");
     const parrot_tte_cfg& c = t->cfg;
     if (L >= c.max_len) return fail(PARROT_E_RANGE, "tte_decode: expanded length >= max_len (pe[T] out of range, fft.py:18)");
     hipStream_t s = (hipStream_t)stream;
     Arena sa(state, state_bytes);
-    TteState st = tte_state(t, sa, B, S);
+    TteState st = tte_state(t, sa, Bfull, S);
     Arena a(ws, ws_bytes);
     TteScratch w = tte_scratch(t, a, B, std::max(S, L), true);
     if (!sa.ok || !a.ok) return fail(PARROT_E_NOMEM, "tte_decode: state/workspace too small");
     const int D = c.d_model, V = c.n_codes;
-    hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, st.enc_out, st.cum, st.out_len,
-                       t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D, t->guard > 0.f ? t->gstat : nullptr);
+    // tie-guard statistics: the first group of a batch (row0 = 0) restarts them, later groups append to the list
+    hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, st.enc_out + (size_t)row0 * D * S, st.cum + (size_t)row0 * S,
+                       st.out_len + row0, t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D, t->guard > 0.f ? t->gstat : nullptr, row0 == 0 ? 1 : 0);
     HIP_TRY(hipGetLastError());
     auto dbg = [&](size_t idx, const float* src, size_t n) -> int {
-        if (idx < t->dbg_dec.size() && t->dbg_dec[idx]) HIP_TRY(hipMemcpyAsync(t->dbg_dec[idx], src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (idx < t->dbg_dec.size() && t->dbg_dec[idx])
+            HIP_TRY(hipMemcpyAsync(t->dbg_dec[idx] + (size_t)row0 * D * L, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         return PARROT_OK;
     };
     TRY(dbg(0, w.x, (size_t)B * D * L));
@@ -1614,7 +1620,7 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
     {   // argmax + tie guard: gstat = {count, ids changed, min margin (float bits)} of this decode
         const bool on = t->guard > 0.f;  // (length_regulate_kernel, the first kernel of this decode, has reset gstat)
         hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(64 * ARGMAX_WAVES), 0, s, w.logits, ids, V, L, t->err, t->guard,
-                           on ? t->glist : nullptr, on ? t->gstat : nullptr);
+                           on ? t->glist : nullptr, on ? t->gstat : nullptr, row0);
         HIP_TRY(hipGetLastError());
         if (on) {  // re-evaluate the head of the low-margin positions in fp64 (workgroups beyond the count exit at once)
             // w.f / w.h still hold the last decoder block's relu(conv1) and x + attn: with them the refinement starts one layer
@@ -1623,7 +1629,7 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
             const int F = c.n_filter_ffn;
             hipLaunchKernelGGL(tie_guard_refine_kernel, dim3(TIE_GUARD_MAX), dim3(256), (size_t)(D + (deep ? F : 0)) * sizeof(double), s, w.x,
                                t->head_w, t->head_b, ids, D, V, L, t->glist, t->gstat, deep ? w.f : nullptr, deep ? w.h : nullptr, t->last_w2t,
-                               t->last_b2, F, t->gref);
+                               t->last_b2, F, t->gref, row0);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1632,6 +1638,15 @@ extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t 
         HIP_TRY(hipGetLastError());
     }
     return PARROT_OK;
+}
+extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int64_t* ids, uint8_t* tgt_mask, float* logits,
+                                 void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+    return tte_decode_rows(t, B, S, L, 0, B, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream);
+}
+extern "C" int parrot_tte_decode_rows(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int32_t row0, int32_t n_rows, int64_t* ids,
+                                      uint8_t* tgt_mask, float* logits, void* state, size_t state_bytes, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    return tte_decode_rows(t, B, S, L, row0, n_rows, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream);
 }
 
 extern "C" int parrot_tte_debug_stages(parrot_tte_t* t, float* const* enc_ptrs, float* const* dec_ptrs) {

@@ -15,11 +15,79 @@ from .tte import Parrot
 from .vocoder import CodeGenerator
 
 
+def _default_row_groups():
+    """PARROT_ROW_GROUPS: a group count ("2", the default) or explicit group sizes for one batch size ("16+48": used when they add
+    up to the batch, an even split into as many groups otherwise)."""
+    import os
+    v = os.environ.get("PARROT_ROW_GROUPS", "2")
+    if "+" in v:
+        return [max(1, int(x)) for x in v.split("+")]
+    return max(1, int(v))
+
+
 class SynthesisPipeline:
-    def __init__(self, parrot: Parrot, generator: CodeGenerator):
+    """``row_groups`` (default 2, ``PARROT_ROW_GROUPS``): one batch runs as a software pipeline over groups of its rows -- the TTE
+    decoder of row group g + 1 on a side HIP stream beside the vocoder of group g.  The TTE is a tenth of a step's arithmetic
+    but made of ~100 small launches that leave most of the chip idle; beside the vocoder's chip-filling launches they cost
+    almost nothing.  Results do not depend on the grouping: the encoder, the duration predictor and the expanded length L (pe[L]
+    is indexed by the batch-max length, quirk Q7) are the whole batch's, and every decoder / vocoder kernel works row by row
+    (tests/test_gpu_round4.py::test_row_groups_leave_every_output_bit_unchanged).  Batches with fewer than 16 rows per group
+    run whole."""
+
+    def __init__(self, parrot: Parrot, generator: CodeGenerator, row_groups: Optional[int] = None):
         self.parrot, self.generator = parrot, generator
+        self.row_groups = _default_row_groups() if row_groups is None else row_groups
         self._side: Optional[torch.cuda.Stream] = None
         self._pending: Optional[dict] = None
+
+    def _groups(self, B: int):
+        rg = self.row_groups
+        if isinstance(rg, (list, tuple)):
+            if sum(rg) == B:
+                out, b0 = [], 0
+                for n in rg:
+                    out.append((b0, int(n)))
+                    b0 += int(n)
+                return out
+            rg = len(rg)
+        g = min(max(1, int(rg)), max(1, B // 16))
+        base, rem = divmod(B, g)
+        out, b0 = [], 0
+        for i in range(g):
+            n = base + (1 if i < rem else 0)
+            out.append((b0, n))
+            b0 += n
+        return out
+
+    @torch.no_grad()
+    def _call_grouped(self, batch, spkr, groups) -> Dict[str, torch.Tensor]:
+        par, gen = self.parrot, self.generator
+        dev = batch["phones"].device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
+        ctx = par._encode(batch, status_hooks=(gen._status_hook,))  # whole batch, main stream; host sync for L
+        B, L = ctx["B"], ctx["L"]
+        ids = torch.empty((B, L), dtype=torch.int64, device=dev)
+        tgt = torch.empty((B, L), dtype=torch.uint8, device=dev)
+        if spkr is None and gen.multispkr:
+            spkr = batch["speaker"].reshape(-1, 1)
+        emitted = torch.clamp(ctx["lens"].to(torch.int64) + 1, max=L)  # (host) ids per row as Parrot.infer returns them (Q2)
+        emitted_dev = emitted.to(dev, torch.int32)
+        wav = torch.empty((B, 1, gen.out_samples(L)), dtype=torch.float32, device=dev)
+        side.wait_stream(main)  # the encoder's state, ids / tgt allocations
+        events = []
+        with torch.cuda.stream(side):  # every group's decoder, in row order, on the side stream
+            for b0, n in groups:
+                par._decode(ctx, ids, tgt, None, b0, n)
+                events.append(side.record_event())
+        for t in (ids, tgt):
+            t.record_stream(side)
+        for (b0, n), ev in zip(groups, events):  # each group's vocoder on the caller's stream as soon as its ids exist
+            main.wait_event(ev)
+            gen(code=ids[b0:b0 + n], spkr=None if spkr is None else spkr[b0:b0 + n], unit_lens=emitted_dev[b0:b0 + n], out=wav[b0:b0 + n])
+        return {"wav": wav, "n_samples": gen.out_samples(emitted), "ids": ids, "tgt_mask": tgt.bool(), "lens": ctx["lens"]}
 
     @torch.no_grad()
     def __call__(self, batch: Dict[str, torch.Tensor], spkr: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -27,6 +95,11 @@ class SynthesisPipeline:
         (defaults to the TTE speaker ids).  Returns wav (B,1,hop*L), n_samples (B,) = hop*emitted ids
         per row (rows shorter than L emit len+1 ids, reference quirk Q2), ids, tgt_mask.  wav[b, :, n_samples[b]:] is
         unspecified (padding)."""
+        groups = self._groups(batch["phones"].shape[0])
+        # (the first forward of a handle runs whole: the shims take one synchronous look at the range flags there)
+        if len(groups) > 1 and not self.parrot._probe_pending and self.parrot._handle is not None and self.generator._handle is not None \
+                and not getattr(self.generator, "_probe_pending", False):
+            return self._call_grouped(batch, spkr, groups)
         # the vocoder's device flag of the PREVIOUS call (bad unit id, non-finite waveform: an activation beyond the fp16 split
         # scheme's range) is read with the TTE's length transfer: a checkpoint that leaves the range fails loudly, by default,
         # one call late and at no extra synchronisation (`check()` covers the last call)

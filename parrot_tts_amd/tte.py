@@ -205,9 +205,11 @@ class Parrot(nn.Module):
         raise IndexError(f"{who}: embedding index out of range (code {code})")
 
     @torch.no_grad()
-    def _run(self, batch, want_logits: bool, status_hooks=()):
-        """``status_hooks``: callables ``hook(dst_ptr, stream_ptr) -> name`` that enqueue a copy of another handle's device status
-        flag (the vocoder's, see SynthesisPipeline): they ride on the one device-to-host transfer this method performs anyway."""
+    def _encode(self, batch, status_hooks=()) -> dict:
+        """Phase 1 (encoder, duration predictor) and the ONE device-to-host transfer of the path (the expanded lengths: the
+        reference's own host sync, duration.py:10).  ``status_hooks``: callables ``hook(dst_ptr, stream_ptr) -> name`` that enqueue a
+        copy of another handle's device status flag (the vocoder's, see SynthesisPipeline): they ride on that transfer.
+        Returns the context ``_decode`` continues from."""
         phones = batch["phones"]
         require_cuda(phones, "batch['phones']")
         dev = phones.device
@@ -236,41 +238,72 @@ class Parrot(nn.Module):
                 hooked = [hook(status.data_ptr() + 4 * (B + 1 + i), st) for i, hook in enumerate(status_hooks)]
                 hooked = [h if isinstance(h, tuple) else (h, None) for h in hooked]  # (name, on_nonfinite callback or None)
                 status_h = status.cpu()  # the one host sync the reference also has (duration.py:10)
-                lens_h = status_h[:B]
-                # bad phone / speaker ids of THIS encode (the reference's Embedding IndexError), non-finite logits of the previous
-                # decode, and whatever the hooks watch (the previous vocoder forward): raised here, by default, at no extra sync
-                if int(status_h[B]) == 5:
-                    self._fall_back("a previous decode produced non-finite logits")  # (later batches run in bf16x6; this one is reported)
-                self._raise_status(int(status_h[B]), "tte")
-                for i, (nm, on_nonfinite) in enumerate(hooked):
-                    if int(status_h[B + 1 + i]) == 5 and on_nonfinite is not None:
-                        on_nonfinite()
-                    self._raise_status(int(status_h[B + 1 + i]), nm)
-                L = int(lens_h.max())
-                del ws
-                ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, B, S, L), dtype=torch.uint8, device=dev)
-                ids = torch.empty((B, L), dtype=torch.int64, device=dev)
-                tgt = torch.empty((B, L), dtype=torch.uint8, device=dev)
-                logits = torch.empty((B, L, lib_n_codes(self)), dtype=torch.float32, device=dev) if want_logits else None
-                _lib.check(lib.parrot_tte_decode(self._handle, B, S, L, dptr(ids), dptr(tgt), dptr(logits), dptr(state), state.numel(),
-                                                 dptr(ws), ws.numel(), st))
-                if self._probe_pending:  # first decode of this handle: one synchronous look at the device flag
-                    self._probe_pending = False
-                    if self.range_fallback and int(lib.parrot_tte_precision(self._handle)) == PREC_F16X3:
-                        flag = torch.zeros(1, dtype=torch.int32, device=dev)
-                        _lib.check(lib.parrot_tte_status_peek_async(self._handle, dptr(flag), st))
-                        if int(flag.cpu()) == 5:
-                            _lib.check(lib.parrot_tte_status_async(self._handle, dptr(flag), st))  # handled here: clear it
-                            if self._fall_back("the first decode of this handle produced non-finite logits"):
-                                return self._run(batch, want_logits, status_hooks=())
             except _lib.ParrotHipError as e:
-                if e.code == -2:  # PARROT_E_RANGE <-> the reference's IndexError (pe[T], Embedding)
-                    raise IndexError(str(e)) from None
-                if e.code == -6:  # PARROT_E_NONFINITE (flag raised by an earlier decode)
-                    raise FloatingPointError(str(e)) from None
-                raise
-        return {"ids": ids, "tgt_mask": tgt.bool(), "log_dur": log_dur, "dur": dur, "lens": lens_h, "logits": logits,
-                "src_mask": src_mask}
+                self._reraise(e)
+        lens_h = status_h[:B]
+        # bad phone / speaker ids of THIS encode (the reference's Embedding IndexError), non-finite logits of the previous
+        # decode, and whatever the hooks watch (the previous vocoder forward): raised here, by default, at no extra sync
+        if int(status_h[B]) == 5:
+            self._fall_back("a previous decode produced non-finite logits")  # (later batches run in bf16x6; this one is reported)
+        self._raise_status(int(status_h[B]), "tte")
+        for i, (nm, on_nonfinite) in enumerate(hooked):
+            if int(status_h[B + 1 + i]) == 5 and on_nonfinite is not None:
+                on_nonfinite()
+            self._raise_status(int(status_h[B + 1 + i]), nm)
+        return {"B": B, "S": S, "L": int(lens_h.max()), "dev": dev, "state": state, "log_dur": log_dur, "dur": dur, "lens": lens_h,
+                "src_mask": src_mask, "handle": self._handle}
+
+    @staticmethod
+    def _reraise(e):
+        if e.code == -2:  # PARROT_E_RANGE <-> the reference's IndexError (pe[T], Embedding)
+            raise IndexError(str(e)) from None
+        if e.code == -6:  # PARROT_E_NONFINITE (flag raised by an earlier decode)
+            raise FloatingPointError(str(e)) from None
+        raise e
+
+    @torch.no_grad()
+    def _decode(self, ctx: dict, ids: torch.Tensor, tgt: torch.Tensor, logits: Optional[torch.Tensor], row0: int = 0,
+                n_rows: Optional[int] = None) -> None:
+        """Phase 2 for rows [row0, row0 + n_rows) of the encoded batch, on the CURRENT stream: length regulator, decoder, head,
+        argmax (+ tie guard) into rows row0.. of ``ids`` / ``tgt`` (/ ``logits``), which hold the whole batch.  The expanded length
+        L is the whole batch's (quirk Q7: pe[L] is indexed by the batch-max length), so a row's result does not depend on how the
+        batch is cut into groups.  The scratch buffer is allocated on the current stream."""
+        lib = _lib.lib()
+        B, S, L, dev = ctx["B"], ctx["S"], ctx["L"], ctx["dev"]
+        n = B - row0 if n_rows is None else n_rows
+        ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, n, S, L), dtype=torch.uint8, device=dev)
+        state = ctx["state"]
+        state.record_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.device(dev):
+            try:
+                _lib.check(lib.parrot_tte_decode_rows(self._handle, B, S, L, row0, n, dptr(ids[row0:]), dptr(tgt[row0:]),
+                                                      dptr(logits[row0:]) if logits is not None else None, dptr(state), state.numel(),
+                                                      dptr(ws), ws.numel(), stream_ptr(dev)))
+            except _lib.ParrotHipError as e:
+                self._reraise(e)
+
+    @torch.no_grad()
+    def _run(self, batch, want_logits: bool, status_hooks=()):
+        ctx = self._encode(batch, status_hooks)
+        lib = _lib.lib()
+        B, L, dev = ctx["B"], ctx["L"], ctx["dev"]
+        ids = torch.empty((B, L), dtype=torch.int64, device=dev)
+        tgt = torch.empty((B, L), dtype=torch.uint8, device=dev)
+        logits = torch.empty((B, L, lib_n_codes(self)), dtype=torch.float32, device=dev) if want_logits else None
+        self._decode(ctx, ids, tgt, logits)
+        if self._probe_pending:  # first decode of this handle: one synchronous look at the device flag
+            self._probe_pending = False
+            if self.range_fallback and int(lib.parrot_tte_precision(self._handle)) == PREC_F16X3:
+                flag = torch.zeros(1, dtype=torch.int32, device=dev)
+                with torch.cuda.device(dev):
+                    st = stream_ptr(dev)
+                    _lib.check(lib.parrot_tte_status_peek_async(self._handle, dptr(flag), st))
+                    if int(flag.cpu()) == 5:
+                        _lib.check(lib.parrot_tte_status_async(self._handle, dptr(flag), st))  # handled here: clear it
+                        if self._fall_back("the first decode of this handle produced non-finite logits"):
+                            return self._run(batch, want_logits, status_hooks=())
+        return {"ids": ids, "tgt_mask": tgt.bool(), "log_dur": ctx["log_dur"], "dur": ctx["dur"], "lens": ctx["lens"], "logits": logits,
+                "src_mask": ctx["src_mask"]}
 
     @torch.no_grad()
     def forward_stages(self, batch) -> dict:

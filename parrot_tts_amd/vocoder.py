@@ -324,10 +324,12 @@ class CodeGenerator(nn.Module):
         return code.contiguous(), spkr, lens32
 
     @torch.no_grad()
-    def forward(self, stages: Optional[dict] = None, unit_lens: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+    def forward(self, stages: Optional[dict] = None, unit_lens: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                **kwargs) -> torch.Tensor:
         """``generator(code=..., spkr=...)`` as in the reference.  ``unit_lens`` (B,) int: real units per row of a padded
         (ragged) batch -- every layer then zero-pads at each row's own end, so ``wav[b, :, :unit_lens[b]*hop]`` equals the
-        reference run of that utterance alone (the reference vocoder driver is B=1 only)."""
+        reference run of that utterance alone (the reference vocoder driver is B=1 only).  ``out``: a contiguous float32
+        (B, 1, samples) tensor to write the waveform into (row groups of one batch fill slices of one tensor)."""
         code, spkr, lens32 = self._checked_inputs(kwargs, unit_lens)
         dev = code.device
         self._current_handle(dev)
@@ -346,7 +348,12 @@ class CodeGenerator(nn.Module):
         if key not in self._ws:
             self._ws = {key: torch.empty(lib.parrot_voc_workspace_bytes(self._handle, B, U), dtype=torch.uint8, device=dev)}
         ws = self._ws[key]
-        wav = torch.empty((B, 1, self.out_samples(U)), dtype=torch.float32, device=dev)
+        if out is not None:
+            if out.shape != (B, 1, self.out_samples(U)) or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
+                raise ValueError("out must be a contiguous float32 (B, 1, out_samples(U)) tensor on the inputs' device")
+            wav = out
+        else:
+            wav = torch.empty((B, 1, self.out_samples(U)), dtype=torch.float32, device=dev)
         stage_ptrs = None
         if stages is not None:  # tests: capture conv_pre / ups_i / mrf_i activations
             names = ["conv_pre"]
@@ -363,7 +370,7 @@ class CodeGenerator(nn.Module):
             _lib.check(lib.parrot_voc_forward_feats(self._handle, dptr(code), dptr(spkr), dptr(feats), n_feat, dptr(lens32), B, U,
                                                     dptr(wav), stage_ptrs, dptr(ws), ws.numel(), stream_ptr(dev)))
         if self._first_forward_overflowed(dev):
-            return self.forward(stages=stages, unit_lens=unit_lens, **kwargs)
+            return self.forward(stages=stages, unit_lens=unit_lens, out=out, **kwargs)
         if _CHECK_FINITE and not bool(torch.isfinite(wav).all()):
             # the default fp16x3 scheme needs |activation| < 8190 (include/parrot_hip.h): beyond that the output is inf/NaN
             raise FloatingPointError("non-finite waveform: an activation left the fp16 split scheme's range; "

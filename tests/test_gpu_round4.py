@@ -234,3 +234,75 @@ def test_merged_vs_unmerged_projections_and_the_deep_tie_guard(tmp_path, shape):
     # the default (merged) is not further from fp64 than the unmerged evaluation, beyond run-to-run rounding
     assert row["logits_err_vs_fp64_merged"] <= row["logits_err_vs_fp64_unmerged"] * 1.25 + 1e-6, row
     assert row["ids_mismatch_merged"] == 0, row
+
+
+def _pipeline_with(tmp_path, B, S, ragged, seed, row_groups, tie_head=False, forced_duration=None):
+    cfg, h = synth.small_tte_config(), synth.small_voc_config()
+    cfg["path"]["root_path"] = str(tmp_path)
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({"a": 0, "b": 1}, f)
+    vocab, n_spk = 30, 2
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=seed, forced_duration=forced_duration)
+    for k in list(tsd):  # the small vocoder knows 100 units
+        if k.endswith("head.weight") or k.endswith("head.bias"):
+            tsd[k] = tsd[k].clone()
+            tsd[k][100:] = -10.0 if k.endswith("bias") else 0.0
+    if tie_head:  # two identical head rows win everywhere: every position is an exact tie (test_gpu_round3's guard checkpoint)
+        hw, hb = tsd["head.weight"], tsd["head.bias"]
+        hw[:] = hw * 0.01
+        hw[17] = hw[5] = torch.randn_like(hw[5])
+        hb[:] = -50.0
+        hb[17] = hb[5] = 3.0
+    vsd = synth.synth_voc_state_dict(h, seed=3)
+    parrot = Parrot(cfg, vocab, 0)
+    parrot.load_state_dict(tsd)
+    batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=seed + 1, ragged=ragged)
+    pipe = SynthesisPipeline(parrot.eval().to(DEV), _gen(h, vsd), row_groups=row_groups)
+    return pipe, batch, tsd, cfg
+
+
+def test_row_groups_leave_every_output_bit_unchanged(tmp_path):
+    """The in-batch software pipeline (SynthesisPipeline row groups: decoder of rows g + 1 on a side stream beside the vocoder of
+    rows g, parrot_tte_decode_rows) must be invisible in the results: ids, masks, lengths and every valid waveform sample of a
+    ragged batch equal the whole-batch run's bit for bit, for even and uneven groupings."""
+    outs = {}
+    for g in (1, 2, 3):
+        pipe, batch, _, _ = _pipeline_with(tmp_path, 50, 13, True, 5, g)
+        gb = {k: v.to(DEV) for k, v in batch.items()}
+        pipe(gb)  # first call of the handles: whole batch (range probe)
+        assert len(pipe._groups(50)) == g
+        o = pipe(gb)
+        pipe.check()
+        torch.cuda.synchronize()
+        outs[g] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in o.items()}
+    ref = outs[1]
+    hop = 320
+    for g in (2, 3):
+        o = outs[g]
+        assert torch.equal(o["ids"], ref["ids"]) and torch.equal(o["tgt_mask"], ref["tgt_mask"]) and torch.equal(o["lens"], ref["lens"])
+        assert torch.equal(o["n_samples"], ref["n_samples"])
+        for b in range(50):
+            n = int(ref["n_samples"][b])
+            assert n % hop == 0 and torch.equal(o["wav"][b, :, :n], ref["wav"][b, :, :n]), (g, b)
+
+
+def test_row_groups_keep_the_tie_guard_working(tmp_path):
+    """Every position of this checkpoint is an exact tie between codes 5 and 17 (torch.argmax: the first).  Grouped decoding appends
+    each group's low-margin positions to the batch's guard list and refines exactly its own entries: all ids are 5 (as the oracle's),
+    the statistics cover the whole batch."""
+    pipe, batch, tsd, cfg = _pipeline_with(tmp_path, 40, 3, False, 8, 2, tie_head=True, forced_duration=2)
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    pipe(gb)
+    o = pipe(gb)
+    pipe.check()
+    gs = pipe.parrot.guard_stats()
+    with torch.no_grad():
+        ref = O.tte_forward(tsd, cfg, batch)
+    mask = ref["tgt_mask"]
+    n_pos = int(mask.numel())  # L = 6 for every row: 240 positions <= the guard list's 256 entries
+    assert n_pos <= 256 and gs["n_guarded"] == n_pos, (gs, n_pos)
+    ids = o["ids"].cpu()
+    assert bool((ids == 5).all())
+    assert torch.equal(ids[mask], torch.argmax(ref["logits"], -1)[mask])
+    lg, pos = pipe.parrot.guard_logits()
+    assert lg.shape[0] == n_pos and sorted(set(int(b) for b in pos[:, 0])) == list(range(40))  # batch rows, not rows of a group
