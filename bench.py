@@ -236,13 +236,40 @@ def main():
         def drain():  # every submitted batch is finished inside the region that submitted it
             return finish(pipe.flush()) if overlap else None
 
+        names = tile_names(precision)
+
+        def read_rows(n_steps):
+            prof = (C.c_double * (4 * len(names)))()
+            _lib.check(lib.parrot_prof_end(prof, len(names)))
+            out = []
+            for i, nm in enumerate(names):
+                n, tms, fl, by = prof[4 * i: 4 * i + 4]
+                if n > 0:
+                    out.append({"kernel": nm, "row": i, "launches_per_step": n / n_steps, "avg_us": tms / n * 1e3, "ms_per_step": tms / n_steps,
+                                "tflops": fl / tms / 1e9, "alg_gbs": by / tms / 1e6})
+            return out
+
+        # W untimed warm-up steps.  The last two of them (one more step when W < 3) run with HIP events around EVERY conv launch:
+        # the per-kernel table (`all_conv_kernels`) and the choice of the dominant kernel.  The timed region then carries events
+        # around the dominant kernel's launches only -- `roofline.achieved` is measured there, live, as the contract asks -- because
+        # a pair of event records around all ~130 launches of a step is itself 0.6 ms of a B = 64 step (3 %) and 0.4 ms of a 2 ms
+        # single-utterance step: measurement overhead, not work of the path (tools/step_time.py --prof shows the A/B).
+        n_table = 2 if warmup >= 3 else 1
         wav = None
-        for _ in range(warmup):
+        for _ in range(max(warmup - n_table, 1 if warmup else 0)):
             wav = step()
         wav = drain() if overlap and warmup else wav
         fence()
-        gather_ev.clear()
         lib.parrot_prof_begin()
+        for _ in range(n_table):
+            wav = step()
+        wav = drain() if overlap else wav
+        fence()
+        table = read_rows(n_table)
+        table.sort(key=lambda r: -r["ms_per_step"])
+        dom_row = table[0]["row"] if table else 0
+        gather_ev.clear()
+        _lib.check(lib.parrot_prof_begin_row(dom_row))
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
@@ -255,20 +282,20 @@ def main():
         in_use = {"tte": parrot.precision_in_use if workload == "full" else precision, "vocoder": gen.precision_in_use}
         if any(v not in (None, precision) for v in in_use.values()):
             raise SystemExit(f"bench.py: asked for precision {precision} but the handles ran as {in_use} (non-finite output -> fallback)")
-        names = tile_names(precision)
-        prof = (C.c_double * (4 * len(names)))()
-        _lib.check(lib.parrot_prof_end(prof, len(names)))
+        timed = read_rows(steps)  # the dominant kernel's launches of the timed region
         g_ms = sum(a_.elapsed_time(b_) for a_, b_ in gather_ev) / max(steps, 1)
         t = torch.tensor([elapsed, g_ms], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         run.gather_ms = float(t[1].item())
         rows = []
-        for i, nm in enumerate(names):
-            n, tms, fl, by = prof[4 * i: 4 * i + 4]
-            if n > 0:
-                rows.append({"kernel": nm, "launches_per_step": n / steps, "avg_us": tms / n * 1e3, "ms_per_step": tms / steps,
-                             "tflops": fl / tms / 1e9, "alg_gbs": by / tms / 1e6})
+        for r in table:
+            r = dict(r)
+            r["measured_in"] = "untimed warm-up steps with events around every launch"
+            if timed and r["row"] == timed[0]["row"]:
+                r.update(timed[0])
+                r["measured_in"] = "the timed region (events around this kernel's launches only)"
+            rows.append(r)
         # per row: fraction of the scheme's MFMA roof and of the 8 TB/s HBM peak (algorithmic bytes), and which resource binds the
         # kernel as measured (counters, phase traces, instruction probes)
         n_mf = SCHEMES[precision][1]
@@ -291,6 +318,7 @@ def main():
             else:
                 r["bound"] = "mfma fp32"
         rows.sort(key=lambda r: -r["ms_per_step"])
+        rows.sort(key=lambda r: 0 if (timed and r["row"] == timed[0]["row"]) else 1)  # (stable: the timed-region row leads)
         n_samples = world * B * (wav.shape[-1] if wav is not None else 4 * S * 320)
         del pipe, parrot, gen
         return float(t[0].item()), rows, n_samples, (cfg, h, tsd, vsd)

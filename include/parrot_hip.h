@@ -111,7 +111,12 @@ int parrot_debug_copy(const float* src, float* dst, size_t n, void* stream);
  * its power limit -- shape 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16; random operands (constant_data = 0) or one
  * constant (1); two waves per SIMD, ~20-40 ms.  Synchronises the device.  TFLOP/s of 16-bit MFMA work in *tflops_out. */
 int parrot_debug_mfma_ceiling(int32_t shape, int32_t constant_data, double* tflops_out);
+/* Per-launch timing of the conv kernels (HIP events on the launch stream, aggregated per kernel row: bench.py's roofline
+ * object).  parrot_prof_begin times every launch; parrot_prof_begin_row only the launches of one row (the dominant kernel):
+ * event records around every launch of a step are themselves 3 % of a B = 64 step and 20 % of a single-utterance one.
+ * parrot_prof_end: out[4 row + {0,1,2,3}] = {launches, total ms, algorithmic flops, algorithmic bytes}. */
 int parrot_prof_begin(void);
+int parrot_prof_begin_row(int32_t row);
 int parrot_prof_end(double* out, int32_t n_cfg);
 
 /* ------------------------------------------------------------------------------------------

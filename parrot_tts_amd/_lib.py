@@ -78,6 +78,7 @@ SIGNATURES = {
     "parrot_debug_copy": (C.c_int, [vp, vp, sz, vp]),
     "parrot_debug_mfma_ceiling": (C.c_int, [i32, i32, C.POINTER(C.c_double)]),
     "parrot_prof_begin": (C.c_int, []),
+    "parrot_prof_begin_row": (C.c_int, [i32]),
     "parrot_prof_end": (C.c_int, [C.POINTER(C.c_double), i32]),
     "parrot_voc_create": (C.c_int, [C.POINTER(vp), C.POINTER(VocCfg), C.POINTER(VocWeights)]),
     "parrot_voc_create_ex": (C.c_int, [C.POINTER(vp), C.POINTER(VocCfg), C.POINTER(VocWeights), i32, i32]),

@@ -16,23 +16,25 @@ from .vocoder import CodeGenerator
 
 
 def _default_row_groups():
-    """PARROT_ROW_GROUPS: a group count ("2", the default) or explicit group sizes for one batch size ("16+48": used when they add
-    up to the batch, an even split into as many groups otherwise)."""
+    """PARROT_ROW_GROUPS: a group count ("1", the default: off) or explicit group sizes for one batch size ("16+48": used when they
+    add up to the batch, an even split into as many groups otherwise)."""
     import os
-    v = os.environ.get("PARROT_ROW_GROUPS", "2")
+    v = os.environ.get("PARROT_ROW_GROUPS", "1")
     if "+" in v:
         return [max(1, int(x)) for x in v.split("+")]
     return max(1, int(v))
 
 
 class SynthesisPipeline:
-    """``row_groups`` (default 2, ``PARROT_ROW_GROUPS``): one batch runs as a software pipeline over groups of its rows -- the TTE
-    decoder of row group g + 1 on a side HIP stream beside the vocoder of group g.  The TTE is a tenth of a step's arithmetic
-    but made of ~100 small launches that leave most of the chip idle; beside the vocoder's chip-filling launches they cost
-    almost nothing.  Results do not depend on the grouping: the encoder, the duration predictor and the expanded length L (pe[L]
-    is indexed by the batch-max length, quirk Q7) are the whole batch's, and every decoder / vocoder kernel works row by row
-    (tests/test_gpu_round4.py::test_row_groups_leave_every_output_bit_unchanged).  Batches with fewer than 16 rows per group
-    run whole."""
+    """``row_groups`` (default 1 = off, ``PARROT_ROW_GROUPS``): one batch can run as a software pipeline over groups of its rows --
+    the TTE decoder of row group g + 1 on a side HIP stream beside the vocoder of group g (parrot_tte_decode_rows).  Results do not
+    depend on the grouping: the encoder, the duration predictor and the expanded length L (pe[L] is indexed by the batch-max
+    length, quirk Q7) are the whole batch's, and every decoder / vocoder kernel works row by row
+    (tests/test_gpu_round4.py::test_row_groups_leave_every_output_bit_unchanged).  Measured at B = 64 x 256 units it does NOT pay:
+    18.6 ms whole, 19.1 ms in two groups, 21.2 ms in three (tools/step_time.py) -- a 32-row decoder is hardly shorter than a 64-row
+    one (its launches are latency-bound) and two 32-row vocoder passes cost 0.3 ms more than one 64-row pass, which is more than
+    the hidden half decoder saves.  Kept as an option for pipelines whose vocoder batch is capped anyway.  Batches with fewer than
+    16 rows per group run whole."""
 
     def __init__(self, parrot: Parrot, generator: CodeGenerator, row_groups: Optional[int] = None):
         self.parrot, self.generator = parrot, generator
@@ -74,19 +76,28 @@ class SynthesisPipeline:
         if spkr is None and gen.multispkr:
             spkr = batch["speaker"].reshape(-1, 1)
         emitted = torch.clamp(ctx["lens"].to(torch.int64) + 1, max=L)  # (host) ids per row as Parrot.infer returns them (Q2)
-        emitted_dev = emitted.to(dev, torch.int32)
+        # the same on the device, from the lengths the encoder left there: a host-to-device copy of `emitted` would be a pageable
+        # transfer, i.e. the host would wait for the whole decoder before it could enqueue the first vocoder kernel
+        emitted_dev = torch.clamp(ctx["lens_dev"] + 1, max=L)
         wav = torch.empty((B, 1, gen.out_samples(L)), dtype=torch.float32, device=dev)
         side.wait_stream(main)  # the encoder's state, ids / tgt allocations
-        events = []
-        with torch.cuda.stream(side):  # every group's decoder, in row order, on the side stream
-            for b0, n in groups:
-                par._decode(ctx, ids, tgt, None, b0, n)
-                events.append(side.record_event())
         for t in (ids, tgt):
             t.record_stream(side)
-        for (b0, n), ev in zip(groups, events):  # each group's vocoder on the caller's stream as soon as its ids exist
+
+        def decode(g):
+            b0, n = groups[g]
+            with torch.cuda.stream(side):  # every group's decoder, in row order, on the side stream
+                par._decode(ctx, ids, tgt, None, b0, n)
+                return side.record_event()
+
+        # enqueue order = the order the GPU should see the work in: decoder of group 0, then vocoder of group g right before the
+        # decoder of group g + 2 ... so that the first vocoder kernels are in their queue when the first decoder finishes
+        ev = decode(0)
+        for g, (b0, n) in enumerate(groups):
+            nxt = decode(g + 1) if g + 1 < len(groups) else None
             main.wait_event(ev)
             gen(code=ids[b0:b0 + n], spkr=None if spkr is None else spkr[b0:b0 + n], unit_lens=emitted_dev[b0:b0 + n], out=wav[b0:b0 + n])
+            ev = nxt
         return {"wav": wav, "n_samples": gen.out_samples(emitted), "ids": ids, "tgt_mask": tgt.bool(), "lens": ctx["lens"]}
 
     @torch.no_grad()
@@ -111,7 +122,9 @@ class SynthesisPipeline:
         L = ids.shape[1]
         emitted = torch.clamp(r["lens"].to(torch.int64) + 1, max=L)  # ids per row as Parrot.infer returns them (Q2)
         # each row is vocoded with its own sequence end, i.e. exactly as the reference would vocode that row's ids alone
-        wav = self.generator(code=ids, spkr=spkr, unit_lens=emitted)
+        # (the lengths are clamped on the DEVICE, from the copy the encoder left there: handing the host tensor over would be a
+        #  pageable host-to-device copy, which blocks the host until the decoder has drained -- 0.2-0.3 ms of idle GPU per batch)
+        wav = self.generator(code=ids, spkr=spkr, unit_lens=torch.clamp(r["lens_dev"] + 1, max=L))
         return {"wav": wav, "n_samples": self.generator.out_samples(emitted), "ids": ids, "tgt_mask": r["tgt_mask"], "lens": r["lens"]}
 
     def check(self) -> None:
@@ -144,7 +157,7 @@ class SynthesisPipeline:
             if spkr is None and self.generator.multispkr:
                 spkr = batch["speaker"].reshape(-1, 1)
             emitted = torch.clamp(r["lens"].to(torch.int64) + 1, max=ids.shape[1])
-            emitted_dev = emitted.to(dev, torch.int32)
+            emitted_dev = torch.clamp(r["lens_dev"] + 1, max=ids.shape[1])
             self._pending = {"ids": ids, "spkr": spkr, "emitted": emitted, "emitted_dev": emitted_dev, "tgt_mask": r["tgt_mask"],
                              "lens": r["lens"], "event": self._side.record_event()}
         return done

@@ -251,7 +251,7 @@ class Parrot(nn.Module):
                 on_nonfinite()
             self._raise_status(int(status_h[B + 1 + i]), nm)
         return {"B": B, "S": S, "L": int(lens_h.max()), "dev": dev, "state": state, "log_dur": log_dur, "dur": dur, "lens": lens_h,
-                "src_mask": src_mask, "handle": self._handle}
+                "lens_dev": lens, "src_mask": src_mask, "handle": self._handle}
 
     @staticmethod
     def _reraise(e):
@@ -303,7 +303,7 @@ class Parrot(nn.Module):
                         if self._fall_back("the first decode of this handle produced non-finite logits"):
                             return self._run(batch, want_logits, status_hooks=())
         return {"ids": ids, "tgt_mask": tgt.bool(), "log_dur": ctx["log_dur"], "dur": ctx["dur"], "lens": ctx["lens"], "logits": logits,
-                "src_mask": ctx["src_mask"]}
+                "src_mask": ctx["src_mask"], "lens_dev": ctx["lens_dev"]}
 
     @torch.no_grad()
     def forward_stages(self, batch) -> dict:
