@@ -652,14 +652,27 @@ struct parrot_voc {
     int mrf_streams = 1;
     bool mrf_auto = true;
     std::mutex side_mu;  // the side streams / events are the handle's: concurrent callers enqueue their fork-join sequences one at a time
-    hipStream_t side[PARROT_MAX_KERNELS] = {};
-    hipEvent_t ev_fork = nullptr, ev_last[PARROT_MAX_KERNELS] = {};
+    struct StreamSet {
+        hipStream_t side[PARROT_MAX_KERNELS] = {};
+        hipEvent_t ev_fork = nullptr, ev_last[PARROT_MAX_KERNELS] = {};
+    } ss[1];
+    // chunk lanes of the chunk-streamed forward (lane 0 is the caller's stream)
+    static constexpr int MAX_LANES = 4;
+    hipStream_t lane_stream[MAX_LANES] = {};
+    hipEvent_t ev_lane_fork = nullptr, ev_lane_join[MAX_LANES] = {};
     float* dbg_absmax = nullptr;       // parrot_voc_debug_absmax: (n_stages + 2) device floats, max |conv input| per group (caller-owned)
     ~parrot_voc() {
-        for (hipStream_t q : side)
-            if (q) (void)hipStreamDestroy(q);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        for (hipEvent_t e : ev_last)
+        for (StreamSet& q : ss) {
+            for (hipStream_t st : q.side)
+                if (st) (void)hipStreamDestroy(st);
+            if (q.ev_fork) (void)hipEventDestroy(q.ev_fork);
+            for (hipEvent_t e : q.ev_last)
+                if (e) (void)hipEventDestroy(e);
+        }
+        for (hipStream_t st : lane_stream)
+            if (st) (void)hipStreamDestroy(st);
+        if (ev_lane_fork) (void)hipEventDestroy(ev_lane_fork);
+        for (hipEvent_t e : ev_lane_join)
             if (e) (void)hipEventDestroy(e);
         for (uint16_t* q : rb_stream)
             if (q) (void)hipFree(q);
@@ -735,10 +748,17 @@ static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const 
         v->mrf_auto = (e == nullptr);
         v->mrf_streams = (on && cfg->n_kernels > 1) ? cfg->n_kernels : 1;
         if (v->mrf_streams > 1) {
-            for (int j = 1; j < v->mrf_streams; ++j) HIP_TRY(hipStreamCreateWithFlags(&v->side[j], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
-            for (int j = 0; j < v->mrf_streams; ++j) HIP_TRY(hipEventCreateWithFlags(&v->ev_last[j], hipEventDisableTiming));
+            for (parrot_voc::StreamSet& q : v->ss) {
+                for (int j = 1; j < v->mrf_streams; ++j) HIP_TRY(hipStreamCreateWithFlags(&q.side[j], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&q.ev_fork, hipEventDisableTiming));
+                for (int j = 0; j < v->mrf_streams; ++j) HIP_TRY(hipEventCreateWithFlags(&q.ev_last[j], hipEventDisableTiming));
+            }
         }
+        for (int l = 1; l < parrot_voc::MAX_LANES; ++l) {
+            HIP_TRY(hipStreamCreateWithFlags(&v->lane_stream[l], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&v->ev_lane_join[l], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&v->ev_lane_fork, hipEventDisableTiming));
     }
     // ConvTranspose1d(k, stride u, padding (k - u) // 2) (models.py:80-83) yields T u samples for even k - u (every shipped
     // config) and T u + 1 for odd k - u: lengths are taken from the convs' own out_len chain (voc_out_len), ragged rows carry
@@ -992,13 +1012,16 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
 // (one rule for the workspace size and for the forward pass)
 static int voc_streams(const parrot_voc* v, int B, int U) { return (v->mrf_auto && (long)B * U > 8192) ? 1 : v->mrf_streams; }
 
-extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t U) {
-    if (!v || B <= 0 || U <= 0) return 0;
+static size_t voc_ws_bytes(const parrot_voc* v, int B, int U, int ns) {
     Arena a(nullptr, 0);
     a.take<float>((size_t)B * v->cfg.model_in_dim * U);
     const size_t mx = voc_max_act(v, B, U);
-    for (int i = 0; i < 3 + 3 * voc_streams(v, B, U); ++i) a.take<float>(mx);  // stage in / ups out / MRF sum + (T1, RA, RB) per concurrent branch
+    for (int i = 0; i < 3 + 3 * ns; ++i) a.take<float>(mx);  // stage in / ups out / MRF sum + (T1, RA, RB) per concurrent branch
     return align_up(a.off, 256);
+}
+extern "C" size_t parrot_voc_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t U) {
+    if (!v || B <= 0 || U <= 0) return 0;
+    return voc_ws_bytes(v, B, U, voc_streams(v, B, U));
 }
 
 // Receptive field of the generator in units, either side of an output frame: the interval [tau, tau] of one waveform sample is
@@ -1034,7 +1057,7 @@ extern "C" int parrot_voc_receptive_units(const parrot_voc_t* v) { return v ? vo
 
 static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_stride, const int64_t* spkr, const float* feats,
                             int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
-                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream, int ns_sized = 0);
+                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream, int ns_sized = 0, int lane = 0);
 
 extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
                                   int32_t U, float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
@@ -1052,14 +1075,25 @@ extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, co
 // for the shipped one) of real context on both sides and only their own samples are copied into wav_out -- equal to the
 // whole-utterance forward, with the activation memory of chunk_units + 2 halo_units units.  Chunks that touch a true sequence
 // edge contain the edge.
+// Chunk lanes: consecutive chunks are independent (each is vocoded with its own halo), so several are kept in flight -- chunk c on
+// lane c % n, each lane with its own stream, scratch and workspace, and WITHOUT the MRF branch streams: one 256-unit chunk of a
+// B = 8 batch is a ninth of the BASELINE batch, its launches leave CUs idle that the other lanes' launches fill, and whole chunks
+// overlap better than the three branches of one (B = 8 x 1500 units in 256-unit chunks: 15.9 ms one chunk at a time with branch
+// streams, 15.5 with two lanes of three branch streams, 13.4 with two plain lanes; whole utterance 12.0).  PARROT_CHUNK_LANES=1..4.
+static int chunk_lanes() {
+    static const int n = [] { const char* e = getenv("PARROT_CHUNK_LANES"); const int q = e ? atoi(e) : 2; return std::min(std::max(q, 1), (int)parrot_voc::MAX_LANES); }();
+    return n;
+}
 extern "C" size_t parrot_voc_chunked_workspace_bytes(const parrot_voc_t* v, int32_t B, int32_t chunk_units, int32_t halo_units) {
     if (!v || B <= 0 || chunk_units <= 0) return 0;
     const int halo = halo_units < 0 ? voc_receptive_units(v) : halo_units;
     const int span = chunk_units + 2 * halo;
     Arena a(nullptr, 0);
-    a.take<float>((size_t)B * span * v->up_total);
-    a.take<int32_t>((size_t)B);
-    a.off = align_up(a.off, 256) + parrot_voc_workspace_bytes(v, B, span);
+    for (int lane = 0; lane < chunk_lanes(); ++lane) {
+        a.take<float>((size_t)B * span * v->up_total);
+        a.take<int32_t>((size_t)B);
+        a.off = align_up(a.off, 256) + voc_ws_bytes(v, B, span, 1);
+    }
     return align_up(a.off, 256);
 }
 extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
@@ -1074,33 +1108,52 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
     const int halo = halo_units < 0 ? voc_receptive_units(v) : halo_units;
     const int span = chunk_units + 2 * halo, hop = v->up_total;
     hipStream_t s = (hipStream_t)stream;
+    const int n_chunks = (U + chunk_units - 1) / chunk_units;
+    const int n_lanes = std::min(chunk_lanes(), n_chunks);
     Arena a(ws, ws_bytes);
-    float* tmp = a.take<float>((size_t)B * span * hop);
-    int32_t* lens = a.take<int32_t>((size_t)B);
-    a.off = align_up(a.off, 256);
-    const size_t inner = parrot_voc_workspace_bytes(v, B, span);
-    const int ns_span = voc_streams(v, B, span);  // (what parrot_voc_workspace_bytes(v, B, span) reserved branch temporaries for)
-    if (!a.ok || a.off + inner > ws_bytes) return fail(PARROT_E_NOMEM, "voc_forward_chunked: workspace too small");
-    void* inner_ws = (char*)ws + a.off;
-    for (int start = 0; start < U; start += chunk_units) {
+    const size_t inner = voc_ws_bytes(v, B, span, 1);
+    float* tmp[parrot_voc::MAX_LANES] = {};
+    int32_t* lens[parrot_voc::MAX_LANES] = {};
+    void* inner_ws[parrot_voc::MAX_LANES] = {};
+    for (int lane = 0; lane < n_lanes; ++lane) {
+        tmp[lane] = a.take<float>((size_t)B * span * hop);
+        lens[lane] = a.take<int32_t>((size_t)B);
+        a.off = align_up(a.off, 256);
+        inner_ws[lane] = (char*)ws + a.off;
+        a.off += inner;
+    }
+    if (!a.ok || a.off > ws_bytes) return fail(PARROT_E_NOMEM, "voc_forward_chunked: workspace too small");
+    std::unique_lock<std::mutex> side_lock(v->side_mu);  // the lane streams and events are the handle's
+    if (n_lanes > 1) {  // the other lanes see what the caller's stream has produced so far (code, spkr, unit_lens)
+        HIP_TRY(hipEventRecord(v->ev_lane_fork, s));
+        for (int l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(v->lane_stream[l], v->ev_lane_fork, 0));
+    }
+    int c = 0;
+    for (int start = 0; start < U; start += chunk_units, ++c) {
+        const int lane = c % n_lanes;
+        hipStream_t sl = lane ? v->lane_stream[lane] : s;
         const int stop = std::min(U, start + chunk_units);
         const int lo = std::max(0, start - halo), hi = std::min(U, stop + halo), n = hi - lo;
         if (unit_lens) {
-            hipLaunchKernelGGL(rebase_lens_kernel, dim3((B + 255) / 256), dim3(256), 0, s, unit_lens, lens, B, lo, n);
+            hipLaunchKernelGGL(rebase_lens_kernel, dim3((B + 255) / 256), dim3(256), 0, sl, unit_lens, lens[lane], B, lo, n);
             HIP_TRY(hipGetLastError());
         }
-        // (every chunk runs with the branch-stream count the workspace was sized for: a trailing chunk with B x n <= 8192 < B x span
-        //  would otherwise ask for 3 + 3 x 3 activation buffers where 3 + 3 were reserved)
-        TRY(voc_forward_impl(v, code + lo, U, spkr, nullptr, 0, unit_lens ? lens : nullptr, B, n, tmp, nullptr, inner_ws, inner, stream, ns_span));
-        HIP_TRY(hipMemcpy2DAsync(wav_out + (size_t)start * hop, (size_t)U * hop * sizeof(float), tmp + (size_t)(start - lo) * hop,
-                                 (size_t)n * hop * sizeof(float), (size_t)(stop - start) * hop * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+        // (one branch stream per chunk: what the lane's workspace was sized for)
+        TRY(voc_forward_impl(v, code + lo, U, spkr, nullptr, 0, unit_lens ? lens[lane] : nullptr, B, n, tmp[lane], nullptr, inner_ws[lane], inner,
+                             (void*)sl, 1, lane));
+        HIP_TRY(hipMemcpy2DAsync(wav_out + (size_t)start * hop, (size_t)U * hop * sizeof(float), tmp[lane] + (size_t)(start - lo) * hop,
+                                 (size_t)n * hop * sizeof(float), (size_t)(stop - start) * hop * sizeof(float), B, hipMemcpyDeviceToDevice, sl));
+    }
+    for (int l = 1; l < n_lanes; ++l) {  // join: the caller's stream continues when every lane has written its chunks
+        HIP_TRY(hipEventRecord(v->ev_lane_join[l], v->lane_stream[l]));
+        HIP_TRY(hipStreamWaitEvent(s, v->ev_lane_join[l], 0));
     }
     return PARROT_OK;
 }
 
 static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_stride, const int64_t* spkr, const float* feats,
                             int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
-                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream, int ns_sized) {
+                            float* const* stage_out, void* ws, size_t ws_bytes, void* stream, int ns_sized, int lane) {
     if (!v || !code || !wav_out || !ws) return fail(PARROT_E_INVALID, "voc_forward: null argument");
     {
         const int base = v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1);
@@ -1117,6 +1170,9 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
     // concurrent MRF branches: the shape's own rule, or -- chunked path -- the count the caller sized the workspace with
     const int ns = ns_sized > 0 ? std::min(ns_sized, v->mrf_streams) : voc_streams(v, B, U);
     const int ns_alloc = ns;  // (parrot_voc_workspace_bytes reserves exactly these)
+    // (chunk lanes run without branch streams: `lane` only documents the caller)
+    (void)lane;
+    const parrot_voc::StreamSet& ss = v->ss[0];
     std::unique_lock<std::mutex> side_lock(v->side_mu, std::defer_lock);
     if (ns > 1) side_lock.lock();
     float* P[3];
@@ -1170,17 +1226,17 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         const size_t n_act = (size_t)B * v->chan(i) * T;
         TRY(snap(1 + 2 * i, X, n_act));
         if (ns > 1) {  // fork: the side streams see the upsampled stage input
-            HIP_TRY(hipEventRecord(v->ev_fork, s));
-            for (int j = 1; j < ns; ++j) HIP_TRY(hipStreamWaitEvent(v->side[j], v->ev_fork, 0));
+            HIP_TRY(hipEventRecord(ss.ev_fork, s));
+            for (int j = 1; j < ns; ++j) HIP_TRY(hipStreamWaitEvent(ss.side[j], ss.ev_fork, 0));
         }
         for (int j = 0; j < nk; ++j) {
             // the longest branch (largest kernel size = last) stays on the caller's stream
             const int slot = (ns > 1) ? (j + 1) % nk : 0;
-            hipStream_t sj = (slot == 0) ? s : v->side[slot];
+            hipStream_t sj = (slot == 0) ? s : ss.side[slot];
             float* T1 = TMP[slot][0];
             float* RA = TMP[slot][1];
             float* RB = TMP[slot][2];
-            hipEvent_t order = (ns > 1 && j > 0) ? v->ev_last[j - 1] : nullptr;  // XS accumulates in branch order (models.py:100-106)
+            hipEvent_t order = (ns > 1 && j > 0) ? ss.ev_last[j - 1] : nullptr;  // XS accumulates in branch order (models.py:100-106)
             const float* r = X;
             const int base = (i * nk + j) * per_rb;
             const int epi_last = (nk == 1 || j == 0) ? EPI_STORE : (j == nk - 1 ? EPI_ADD_DIV : EPI_ADD);
@@ -1210,10 +1266,10 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
                     r = dst;
                 }
             }
-            if (ns > 1) HIP_TRY(hipEventRecord(v->ev_last[j], sj));
+            if (ns > 1) HIP_TRY(hipEventRecord(ss.ev_last[j], sj));
         }
         if (ns > 1)  // join: every branch (and with it every reader of X and of the branch temporaries) is done
-            for (int j = 0; j < nk; ++j) HIP_TRY(hipStreamWaitEvent(s, v->ev_last[j], 0));
+            for (int j = 0; j < nk; ++j) HIP_TRY(hipStreamWaitEvent(s, ss.ev_last[j], 0));
         TRY(snap(2 + 2 * i, XS, n_act));
         ia = (ia + 2) % 3;
     }
