@@ -272,13 +272,23 @@ int parrot_tte_encode(parrot_tte_t*, const int64_t* phones, const uint8_t* src_m
 int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L,
                       int64_t* ids, uint8_t* tgt_mask, float* logits /* nullable */,
                       void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
-/* Phase 2 for rows [row0, row0 + n_rows) of the encoded batch only (B = the batch `state` was encoded with; L = the WHOLE
- * batch's max(out_lens): pe[L] is indexed by the batch-max length whichever rows run, parrot.py:106).  ids / tgt_mask / logits
- * point at the group's own first row ((n_rows, L) ...), ws needs workspace_bytes(n_rows, S, L).  Every decoder kernel works row by
- * row, so a row decoded in a group equals the same row of parrot_tte_decode bit for bit; a caller can hand the first rows to the
- * vocoder while the next group is still decoding on another stream (SynthesisPipeline row groups).  Groups of one batch run in
- * row order on ONE stream: the group with row0 = 0 restarts the tie-guard statistics, later groups add to them. */
-int parrot_tte_decode_rows(parrot_tte_t*, int32_t B, int32_t S, int32_t L, int32_t row0, int32_t n_rows,
+/* Row groups.  Every encoder / decoder kernel works row by row, pe[S] / pe[L] are indexed by the padded length S and by the WHOLE
+ * batch's L = max(out_lens) whichever rows run (fft.py:18, parrot.py:106), so the batch can be cut into row groups that run
+ * one after the other or CONCURRENTLY on several streams ("lanes": the TTE's launches are small, two lanes fill the chip better)
+ * with results identical, bit for bit, to parrot_tte_encode / parrot_tte_decode on the whole batch.
+ * parrot_tte_encode_rows: phase 1 for rows [row0, row0 + n_rows) of a batch of B rows; every pointer argument is the group's own
+ *   first row, `state` is the whole batch's (B rows), ws needs workspace_bytes(n_rows, S, 0).
+ * parrot_tte_decode_rows: phase 2 for such a group; ids / tgt_mask / logits point at the group's first row, ws needs
+ *   workspace_bytes(n_rows, S, L).  `lane` (0..3) selects the tie-guard list the group's low-margin positions go to: groups that
+ *   decode concurrently use different lanes, groups of one lane run in order on one stream.  flags: PARROT_ROWS_GUARD_RESTART on a
+ *   lane's first group of a batch, PARROT_ROWS_NEW_BATCH additionally on the batch's very first call (it resets which lanes the
+ *   guard statistics readers add up). */
+#define PARROT_ROWS_GUARD_RESTART 1
+#define PARROT_ROWS_NEW_BATCH 2
+int parrot_tte_encode_rows(parrot_tte_t*, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker,
+                           int32_t B, int32_t S, int32_t row0, int32_t n_rows, float* log_dur, int64_t* dur, int32_t* out_lens,
+                           void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
+int parrot_tte_decode_rows(parrot_tte_t*, int32_t B, int32_t S, int32_t L, int32_t row0, int32_t n_rows, int32_t lane, int32_t flags,
                            int64_t* ids, uint8_t* tgt_mask, float* logits /* nullable */,
                            void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
 /* Device-side flags.  Synchronises `stream`, clears the flag; returns 0, PARROT_E_RANGE (a bad phone / speaker id <-> the

@@ -105,7 +105,8 @@ SIGNATURES = {
     "parrot_tte_workspace_bytes": (sz, [vp, i32, i32, i32]),
     "parrot_tte_encode": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_decode": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
-    "parrot_tte_decode_rows": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
+    "parrot_tte_encode_rows": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
+    "parrot_tte_decode_rows": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_check": (C.c_int, [vp, vp]),
     "parrot_tte_status_async": (C.c_int, [vp, vp, vp]),
     "parrot_tte_status_peek_async": (C.c_int, [vp, vp, vp]),

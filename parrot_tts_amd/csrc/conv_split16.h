@@ -363,7 +363,9 @@ inline bool split16_wide_fits(long ncols, long rows, int n_mb, int n_cus) {
     return cost160 <= cost128;
 }
 // (k = 3: three steps per 32-channel chunk do not amortise the larger slab -- measured 3-6 % slower than conv_split_kernel)
-inline bool split16_has(int scheme, int k) { return scheme == SchF16x3::ID && (k == 7 || k == 9 || k == 11); }
+// (the single-MFMA modes take it too: with a third of the MFMAs per chunk the 16-channel chunks of conv_split_kernel are bound by
+//  their per-chunk barrier / staging latency -- bf16 step 13.8 -> 11.9 ms, the wide layers 495 -> 746 TF)
+inline bool split16_has(int scheme, int k) { return (scheme == SchF16x3::ID || scheme == SchBf16::ID || scheme == SchF16::ID) && (k == 7 || k == 9 || k == 11); }
 // The small tiles (variants 2 / 3) run alone on their CU and stream their weights from L2 through the vector L1 at 64 B/clk: on a
 // 2 x 2 wave grid both column waves fetch the same row fragments -- 360 KB per 32-channel chunk at k = 11 = 5.6 k clocks against
 // 4.5 k of MFMA (round-3 chunk trace, profiles/r03q_s16_chunk_trace.log).  Their waves are stacked along M instead (each wave all 64 columns): every weight fragment
@@ -412,11 +414,15 @@ inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStr
 hipError_t launch_conv_split16_wide_f16x3(int variant, const ConvParams& p, hipStream_t s);   // csrc/tu_split16_wide.hip
 hipError_t launch_conv_split16_small_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16_small.hip
 hipError_t launch_conv_split16_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16.hip
+hipError_t launch_conv_split16_bf16(int variant, const ConvParams& p, hipStream_t s);   // csrc/tu_split16_single.hip
+hipError_t launch_conv_split16_f16(int variant, const ConvParams& p, hipStream_t s);    // csrc/tu_split16_single.hip
 inline hipError_t launch_conv_split16(int scheme, int variant, const ConvParams& p, hipStream_t s) {
     if (scheme == SchF16x3::ID)
         return (variant == 2 || variant == 3)   ? launch_conv_split16_small_f16x3(variant, p, s)
                : (variant == 1 || variant == 4) ? launch_conv_split16_wide_f16x3(variant, p, s)
                                                 : launch_conv_split16_f16x3(variant, p, s);
+    if (scheme == SchBf16::ID) return launch_conv_split16_bf16(variant, p, s);
+    if (scheme == SchF16::ID) return launch_conv_split16_f16(variant, p, s);
     return hipErrorInvalidValue;
 }
 

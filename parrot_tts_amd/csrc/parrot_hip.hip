@@ -1313,7 +1313,11 @@ struct parrot_tte {
     // tie guard (argmax_cf_kernel / tie_guard_refine_kernel): fp32 head weights (transposed to (D, V)) for the fp64 re-evaluation, the (b, t) list of
     // the last decode's low-margin positions and its statistics {count, min margin bits, ids changed}
     float *head_w = nullptr, *head_b = nullptr;
+    // (one set per decoder lane -- parrot_tte_decode_rows: row groups of one batch may decode concurrently on several streams --
+    //  laid out back to back: lane l's list / statistics / refined logits start at l x the per-lane size)
+    static constexpr int LANES = 4;
     int *glist = nullptr, *gstat = nullptr;
+    int lanes_used = 1;  // bit l: lane l took part in the last decoded batch (host-side bookkeeping of the statistics readers)
     float guard = 1e-4f;
     // ... extended to the last decoder block's FFN output (round 4): for a guarded position the block's conv2 (1x1) + bias +
     // residual are re-evaluated in fp64 from the fp32 activations the block itself produced (relu(conv1) and x + attn), then the
@@ -1484,10 +1488,10 @@ static int tte_create_body(parrot_tte_t** out, const parrot_tte_cfg* cfg, const 
             TRY(upload(&t->last_w2t, wt.data(), wt.size()));
             if (lw.conv2_b) TRY(upload(&t->last_b2, lw.conv2_b, (size_t)D));
         }
-        HIP_TRY(hipMalloc((void**)&t->gref, (size_t)TIE_GUARD_MAX * c.n_codes * sizeof(float)));
-        HIP_TRY(hipMalloc((void**)&t->glist, 2 * TIE_GUARD_MAX * sizeof(int)));
-        HIP_TRY(hipMalloc((void**)&t->gstat, 4 * sizeof(int)));
-        HIP_TRY(hipMemset(t->gstat, 0, 4 * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&t->gref, (size_t)parrot_tte::LANES * TIE_GUARD_MAX * c.n_codes * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&t->glist, (size_t)parrot_tte::LANES * 2 * TIE_GUARD_MAX * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&t->gstat, (size_t)parrot_tte::LANES * 4 * sizeof(int)));
+        HIP_TRY(hipMemset(t->gstat, 0, (size_t)parrot_tte::LANES * 4 * sizeof(int)));
     }
     *out = t.release();
     return PARROT_OK;
@@ -1610,26 +1614,33 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
     return PARROT_OK;
 }
 
-extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, int32_t B,
-                                 int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens, void* state, size_t state_bytes, void* ws,
-                                 size_t ws_bytes, void* stream) {
+// Encode rows [row0, row0 + B) of a batch of Bfull rows: every pointer argument is the GROUP's first row; the group's encoder
+// output / duration prefix sums land in rows row0.. of `state` (sized for Bfull rows).  The encoder works row by row and pe[S] is
+// indexed by the padded length S alone (fft.py:18), so a row's result does not depend on the grouping.
+static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, int32_t Bfull, int32_t S,
+                           int32_t row0, int32_t B, float* log_dur, int64_t* dur, int32_t* out_lens, void* state, size_t state_bytes, void* ws,
+                           size_t ws_bytes, void* stream) {
     if (!t || !phones || !src_mask || !log_dur || !dur || !out_lens || !state || !ws) return fail(PARROT_E_INVALID, "tte_encode: null argument");
-    if (B <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_encode: empty batch");
+    if (Bfull <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_encode: empty batch");
+    if (row0 < 0 || B <= 0 || row0 + B > Bfull) return fail(PARROT_E_INVALID, "tte_encode: row group outside the batch");
     const parrot_tte_cfg& c = t->cfg;
     if (S >= c.max_len) return fail(PARROT_E_RANGE, "tte_encode: sequence length >= max_len (pe[T] out of range, fft.py:18)");
     if (t->spk && !speaker) return fail(PARROT_E_INVALID, "tte_encode: multi-speaker model needs speaker ids");
     hipStream_t s = (hipStream_t)stream;
     Arena sa(state, state_bytes);
-    TteState st = tte_state(t, sa, B, S);
+    TteState st = tte_state(t, sa, Bfull, S);
     Arena a(ws, ws_bytes);
     TteScratch w = tte_scratch(t, a, B, S, false);
     if (!sa.ok || !a.ok) return fail(PARROT_E_NOMEM, "tte_encode: state/workspace too small");
+    st.enc_out += (size_t)row0 * c.d_model * S;
+    st.cum += (size_t)row0 * S;
+    st.out_len += row0;
     const int D = c.d_model;
     hipLaunchKernelGGL(tte_embed_kernel, dim3((S + 63) / 64, (D + 63) / 64, B), dim3(256), 0, s, phones, t->tok, t->pe + (size_t)S * D,
                        w.x, S, D, c.vocab, t->err);
     HIP_TRY(hipGetLastError());
     auto dbg = [&](const std::vector<float*>& v, size_t idx, const float* src, size_t n) -> int {
-        if (idx < v.size() && v[idx]) HIP_TRY(hipMemcpyAsync(v[idx], src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (idx < v.size() && v[idx]) HIP_TRY(hipMemcpyAsync(v[idx] + (size_t)row0 * D * S, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         return PARROT_OK;
     };
     TRY(dbg(t->dbg_enc, 0, w.x, (size_t)B * D * S));
@@ -1657,12 +1668,24 @@ extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const u
     HIP_TRY(hipMemcpyAsync(out_lens, st.out_len, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return PARROT_OK;
 }
+extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, int32_t B,
+                                 int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens, void* state, size_t state_bytes, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    return tte_encode_rows(t, phones, src_mask, speaker, B, S, 0, B, log_dur, dur, out_lens, state, state_bytes, ws, ws_bytes, stream);
+}
+extern "C" int parrot_tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, int32_t B,
+                                      int32_t S, int32_t row0, int32_t n_rows, float* log_dur, int64_t* dur, int32_t* out_lens, void* state,
+                                      size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+    return tte_encode_rows(t, phones, src_mask, speaker, B, S, row0, n_rows, log_dur, dur, out_lens, state, state_bytes, ws, ws_bytes, stream);
+}
 
 // Decode rows [row0, row0 + n) of the batch that parrot_tte_encode left in `state` (B rows).  ids / tgt_mask / logits point at the
 // group's own first row.  L is the WHOLE batch's expanded length (pe[L], parrot.py:106) whichever rows are decoded, and every
 // kernel of the decoder works row by row, so a row decoded in a group equals the same row decoded with the whole batch bit for bit.
 static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L, int32_t row0, int32_t B, int64_t* ids, uint8_t* tgt_mask,
-                           float* logits, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+                           float* logits, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream, int lane, bool guard_restart,
+                           bool new_batch) {
+    if (lane < 0 || lane >= parrot_tte::LANES) return fail(PARROT_E_INVALID, "tte_decode: lane out of range");
     if (!t || !ids || !tgt_mask || !state || !ws) return fail(PARROT_E_INVALID, "tte_decode: null argument");
     if (Bfull <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_decode: empty batch");
     if (row0 < 0 || B <= 0 || row0 + B > Bfull) return fail(PARROT_E_INVALID, "tte_decode: row group outside the encoded batch");
@@ -1676,9 +1699,13 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
     TteScratch w = tte_scratch(t, a, B, std::max(S, L), true);
     if (!sa.ok || !a.ok) return fail(PARROT_E_NOMEM, "tte_decode: state/workspace too small");
     const int D = c.d_model, V = c.n_codes;
-    // tie-guard statistics: the first group of a batch (row0 = 0) restarts them, later groups append to the list
+    // tie-guard state of this lane: a lane's first group of a batch restarts its statistics, later groups of the lane append
+    int* const gstat = t->gstat ? t->gstat + 4 * lane : nullptr;
+    int* const glist = t->glist ? t->glist + (size_t)lane * 2 * TIE_GUARD_MAX : nullptr;
+    float* const gref = t->gref ? t->gref + (size_t)lane * TIE_GUARD_MAX * V : nullptr;
+    t->lanes_used = (new_batch ? 0 : t->lanes_used) | (1 << lane);
     hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, st.enc_out + (size_t)row0 * D * S, st.cum + (size_t)row0 * S,
-                       st.out_len + row0, t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D, t->guard > 0.f ? t->gstat : nullptr, row0 == 0 ? 1 : 0);
+                       st.out_len + row0, t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D, t->guard > 0.f ? gstat : nullptr, guard_restart ? 1 : 0);
     HIP_TRY(hipGetLastError());
     auto dbg = [&](size_t idx, const float* src, size_t n) -> int {
         if (idx < t->dbg_dec.size() && t->dbg_dec[idx])
@@ -1694,7 +1721,7 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
     {   // argmax + tie guard: gstat = {count, ids changed, min margin (float bits)} of this decode
         const bool on = t->guard > 0.f;  // (length_regulate_kernel, the first kernel of this decode, has reset gstat)
         hipLaunchKernelGGL(argmax_cf_kernel, dim3((L + 63) / 64, B), dim3(64 * ARGMAX_WAVES), 0, s, w.logits, ids, V, L, t->err, t->guard,
-                           on ? t->glist : nullptr, on ? t->gstat : nullptr, row0);
+                           on ? glist : nullptr, on ? gstat : nullptr, row0);
         HIP_TRY(hipGetLastError());
         if (on) {  // re-evaluate the head of the low-margin positions in fp64 (workgroups beyond the count exit at once)
             // w.f / w.h still hold the last decoder block's relu(conv1) and x + attn: with them the refinement starts one layer
@@ -1703,8 +1730,8 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
             const int F = c.n_filter_ffn;
             hipLaunchKernelGGL(tie_guard_refine_kernel, dim3(TIE_GUARD_MAX / TG_PER_WG), dim3(256),
                                (size_t)TG_PER_WG * (D + (deep ? F : 0)) * sizeof(double), s, w.x,
-                               t->head_w, t->head_b, ids, D, V, L, t->glist, t->gstat, deep ? w.f : nullptr, deep ? w.h : nullptr, t->last_w2t,
-                               t->last_b2, F, t->gref, row0);
+                               t->head_w, t->head_b, ids, D, V, L, glist, gstat, deep ? w.f : nullptr, deep ? w.h : nullptr, t->last_w2t,
+                               t->last_b2, F, gref, row0);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1716,12 +1743,13 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
 }
 extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int64_t* ids, uint8_t* tgt_mask, float* logits,
                                  void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
-    return tte_decode_rows(t, B, S, L, 0, B, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream);
+    return tte_decode_rows(t, B, S, L, 0, B, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream, 0, true, true);
 }
-extern "C" int parrot_tte_decode_rows(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int32_t row0, int32_t n_rows, int64_t* ids,
-                                      uint8_t* tgt_mask, float* logits, void* state, size_t state_bytes, void* ws, size_t ws_bytes,
-                                      void* stream) {
-    return tte_decode_rows(t, B, S, L, row0, n_rows, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream);
+extern "C" int parrot_tte_decode_rows(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int32_t row0, int32_t n_rows, int32_t lane,
+                                      int32_t flags, int64_t* ids, uint8_t* tgt_mask, float* logits, void* state, size_t state_bytes,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    return tte_decode_rows(t, B, S, L, row0, n_rows, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream, lane,
+                           (flags & PARROT_ROWS_GUARD_RESTART) != 0, (flags & PARROT_ROWS_NEW_BATCH) != 0);
 }
 
 extern "C" int parrot_tte_debug_stages(parrot_tte_t* t, float* const* enc_ptrs, float* const* dec_ptrs) {
@@ -1880,19 +1908,50 @@ extern "C" int parrot_tte_status_async(parrot_tte_t* t, int32_t* dst_dev, void* 
 // Tie-guard statistics of the last decode, copied to dst_dev[0..2] (device memory) on `stream` without synchronising:
 // {positions whose top-2 logit margin was below the guard, ids changed by the fp64 re-evaluation of the head, the smallest
 // margin of the call as float bits}
+static __global__ void guard_stats_sum_kernel(const int* __restrict__ gstat, int mask, int* __restrict__ dst) {
+    int n = 0, ch = 0, mn = 0x7f800000;
+    for (int l = 0; l < parrot_tte::LANES; ++l)
+        if ((mask >> l) & 1) {
+            n += gstat[4 * l];
+            ch += gstat[4 * l + 1];
+            mn = min(mn, gstat[4 * l + 2]);
+        }
+    dst[0] = n; dst[1] = ch; dst[2] = mn;
+}
+// out row i = the i-th guarded position of the batch, lanes in order (each lane holds at most TIE_GUARD_MAX)
+static __global__ void guard_gather_kernel(const float* __restrict__ gref, const int* __restrict__ glist, const int* __restrict__ gstat, int mask,
+                                           int V, int max_n, float* __restrict__ logits, int* __restrict__ list) {
+    const int i = blockIdx.x;
+    int base = 0, lane = -1, j = 0;
+    for (int l = 0; l < parrot_tte::LANES && lane < 0; ++l)
+        if ((mask >> l) & 1) {
+            const int nl = min(gstat[4 * l], TIE_GUARD_MAX);
+            if (i < base + nl) { lane = l; j = i - base; }
+            base += nl;
+        }
+    if (lane < 0 || i >= max_n) return;
+    const float* src = gref + ((size_t)lane * TIE_GUARD_MAX + j) * V;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) logits[(size_t)i * V + v] = src[v];
+    if (threadIdx.x < 2) list[2 * i + threadIdx.x] = glist[((size_t)lane * TIE_GUARD_MAX + j) * 2 + threadIdx.x];
+}
 extern "C" int parrot_tte_guard_stats_async(parrot_tte_t* t, int32_t* dst_dev, void* stream) {
     if (!t || !dst_dev) return fail(PARROT_E_INVALID, "tte_guard_stats: null argument");
-    HIP_TRY(hipMemcpyAsync(dst_dev, t->gstat, 3 * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (!t->gstat) {
+        HIP_TRY(hipMemsetAsync(dst_dev, 0, 3 * sizeof(int), (hipStream_t)stream));
+        return PARROT_OK;
+    }
+    hipLaunchKernelGGL(guard_stats_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t->gstat, t->lanes_used, dst_dev);
+    HIP_TRY(hipGetLastError());
     return PARROT_OK;
 }
 // Refined (fp64-evaluated, rounded to fp32) logits of the guarded positions of the last decode: logits_dev (max_n x V floats) and
-// their (b, t) pairs list_dev (2 max_n ints), device memory, no synchronisation; the count is guard_stats[0] (capped at 256).
+// their (b, t) pairs list_dev (2 max_n ints), device memory, no synchronisation; the count is guard_stats[0] (at most 256 per decoder lane).
 extern "C" int parrot_tte_guard_logits(parrot_tte_t* t, float* logits_dev, int32_t* list_dev, int32_t max_n, void* stream) {
     if (!t || !logits_dev || !list_dev || max_n <= 0) return fail(PARROT_E_INVALID, "tte_guard_logits: null argument");
     if (!t->gref) return fail(PARROT_E_UNSUPPORTED, "tte_guard_logits: the tie guard of this handle is off");
-    const int n = std::min<int>(max_n, TIE_GUARD_MAX);
-    HIP_TRY(hipMemcpyAsync(logits_dev, t->gref, (size_t)n * t->cfg.n_codes * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync(list_dev, t->glist, (size_t)2 * n * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    hipLaunchKernelGGL(guard_gather_kernel, dim3(max_n), dim3(256), 0, (hipStream_t)stream, t->gref, t->glist, t->gstat, t->lanes_used,
+                       t->cfg.n_codes, max_n, logits_dev, list_dev);
+    HIP_TRY(hipGetLastError());
     return PARROT_OK;
 }
 extern "C" int parrot_voc_check(parrot_voc_t* v, void* stream) { return v ? read_flag(v->err, (hipStream_t)stream, "vocoder") : PARROT_E_INVALID; }
