@@ -388,69 +388,46 @@ static __global__ __launch_bounds__(64 * ARGMAX_WAVES) void argmax_cf_kernel(con
     }
 }
 
-// One workgroup per TG_PER_WG guarded positions: logits[v] = head_b[v] + sum_c head_w[v][c] * x[b][c][t] in fp64 (exact products, fp64
+// One workgroup per guarded position: logits[v] = head_b[v] + sum_c head_w[v][c] * x[b][c][t] in fp64 (exact products, fp64
 // sums in channel order: the argmax no longer depends on the accumulation order of the fp32 head), first maximum wins.
 // `hwt` is the head weight TRANSPOSED to (D, V): thread v reads hwt[c][v], coalesced across the workgroup.
 // Deep form (f != NULL; round 4): the position's activation is first re-evaluated one layer earlier, from the last decoder block's
 // own fp32 intermediates -- x[c] = h[c] + b2[c] + sum_j w2t[j][c] * f[j] in fp64 (f = relu(conv1) (B, F, L), h = x + attn (B, D, L),
 // w2t the 1x1 conv2's weight as (F, D): reference modules/fft.py:81,99) -- which removes the fp32 accumulation error of that
 // K = F sum and of the residual add from the refined logits.  `gref` (TIE_GUARD_MAX x V) receives the refined logits.
-// A workgroup streams both weight matrices (2 MB at the shipped sizes) from L2 once for its positions: with one position per
-// workgroup a full list (256 positions: the synthetic bench checkpoint) read 512 MB and took 96 us per decode; four per workgroup
-// read a quarter of that.  Every position's sums keep their order (j, then c ascending), so the refined values do not depend on the grouping.
-constexpr int TG_PER_WG = 4;
 static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const float* __restrict__ x, const float* __restrict__ hwt,
                                                                       const float* __restrict__ hb, int64_t* __restrict__ ids, int D, int V,
                                                                       int L, const int* __restrict__ glist, int* __restrict__ gstat,
                                                                       const float* __restrict__ f, const float* __restrict__ h,
                                                                       const float* __restrict__ w2t, const float* __restrict__ b2, int F,
                                                                       float* __restrict__ gref, int row0 = 0) {
-    // this row group's entries are [gstat[3], gstat[0]) of the list; x / f / h / ids are the group's own buffers (row b - row0)
-    const int n = min(gstat[0], TIE_GUARD_MAX), entry0 = gstat[3] + (int)blockIdx.x * TG_PER_WG;
-    if (entry0 >= n) return;
-    const int np = min(TG_PER_WG, n - entry0);  // positions of this workgroup
-    extern __shared__ double xs_all[];  // per position: D activations (+ F intermediates in the deep form)
+    // this row group's entries are [gstat[3], gstat[0]) of the lane's list; x / f / h / ids are the group's own buffers (row b - row0)
+    const int n = min(gstat[0], TIE_GUARD_MAX), entry = gstat[3] + (int)blockIdx.x;
+    if (entry >= n) return;
+    extern __shared__ double xs[];  // D activations of the position (+ F intermediates in the deep form)
     __shared__ double rv[256];
     __shared__ int ri[256];
-    const int stride = D + (f ? F : 0);
-    int pb[TG_PER_WG], pt[TG_PER_WG];
-#pragma unroll
-    for (int p = 0; p < TG_PER_WG; ++p) {
-        const int e = entry0 + min(p, np - 1);  // (surplus slots repeat the last position: computed, never written)
-        pb[p] = glist[2 * e] - row0;
-        pt[p] = glist[2 * e + 1];
-    }
+    const int b = glist[2 * entry] - row0, t = glist[2 * entry + 1];
     if (f) {
-#pragma unroll
-        for (int p = 0; p < TG_PER_WG; ++p) {
-            double* fs = xs_all + p * stride + D;
-            for (int j = threadIdx.x; j < F; j += 256) fs[j] = (double)f[((size_t)pb[p] * F + j) * L + pt[p]];
-        }
+        double* fs = xs + D;
+        for (int j = threadIdx.x; j < F; j += 256) fs[j] = (double)f[((size_t)b * F + j) * L + t];
         __syncthreads();
         for (int c = threadIdx.x; c < D; c += 256) {
-            double a[TG_PER_WG] = {};
-#pragma unroll 4
-            for (int j = 0; j < F; ++j) {
-                const double w = (double)w2t[(size_t)j * D + c];
-#pragma unroll
-                for (int p = 0; p < TG_PER_WG; ++p) a[p] = fma(w, xs_all[p * stride + D + j], a[p]);
-            }
-#pragma unroll
-            for (int p = 0; p < TG_PER_WG; ++p)  // (conv + bias) + residual, fft.py:99
-                xs_all[p * stride + c] = (a[p] + (b2 ? (double)b2[c] : 0.0)) + (double)h[((size_t)pb[p] * D + c) * L + pt[p]];
+            // (a thread walks F = 1024 weights with one dependent fp64 chain: what bounds it is the number of loads in flight, not
+            //  the arithmetic -- 8 per thread took 96 us for a full list, one position per workgroup; 32 at a time keep the sum's order)
+            double a = 0.0;
+#pragma unroll 32
+            for (int j = 0; j < F; ++j) a = fma((double)w2t[(size_t)j * D + c], fs[j], a);
+            xs[c] = (a + (b2 ? (double)b2[c] : 0.0)) + (double)h[((size_t)b * D + c) * L + t];  // (conv + bias) + residual, fft.py:99
         }
     } else {
-#pragma unroll
-        for (int p = 0; p < TG_PER_WG; ++p)
-            for (int c = threadIdx.x; c < D; c += 256) xs_all[p * stride + c] = (double)x[((size_t)pb[p] * D + c) * L + pt[p]];
+        for (int c = threadIdx.x; c < D; c += 256) xs[c] = (double)x[((size_t)b * D + c) * L + t];
     }
     __syncthreads();
-    double best[TG_PER_WG];
-    int bi[TG_PER_WG];
-#pragma unroll
-    for (int p = 0; p < TG_PER_WG; ++p) { best[p] = -INFINITY; bi[p] = 0x7fffffff; }
+    double best = -INFINITY;
+    int bi = 0x7fffffff;
     for (int v0 = 0; v0 < V; v0 += 1024) {  // four codes per thread and pass: v0 + threadIdx.x + {0, 256, 512, 768}
-        double acc[4][TG_PER_WG] = {};
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
         int vv[4];
         bool ok[4];
 #pragma unroll
@@ -459,48 +436,34 @@ static __global__ __launch_bounds__(256) void tie_guard_refine_kernel(const floa
             ok[q] = vv[q] < V;
             vv[q] = min(vv[q], V - 1);  // (unconditional loads: a predicated load per element would serialise them; the surplus is ignored below)
         }
-#pragma unroll 4
+#pragma unroll 8
         for (int c = 0; c < D; ++c) {
             const float* w = hwt + (size_t)c * V;
-            double wq[4];
+            const double xc = xs[c];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wq[q] = (double)w[vv[q]];
-#pragma unroll
-            for (int p = 0; p < TG_PER_WG; ++p) {
-                const double xc = xs_all[p * stride + c];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q][p] = fma(wq[q], xc, acc[q][p]);
-            }
+            for (int q = 0; q < 4; ++q) acc[q] = fma((double)w[vv[q]], xc, acc[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int p = 0; p < TG_PER_WG; ++p) {
-                const double a = acc[q][p] + (hb ? (double)hb[vv[q]] : 0.0);
-                if (ok[q] && p < np && gref) gref[(size_t)(entry0 + p) * V + vv[q]] = (float)a;
-                if (ok[q] && a > best[p]) { best[p] = a; bi[p] = vv[q]; }  // (codes ascending per thread: the first maximum is kept)
-            }
+        for (int q = 0; q < 4; ++q) {
+            const double a = acc[q] + (hb ? (double)hb[vv[q]] : 0.0);
+            if (ok[q] && gref) gref[(size_t)entry * V + vv[q]] = (float)a;
+            if (ok[q] && a > best) { best = a; bi = vv[q]; }  // (codes ascending per thread: the first maximum is kept)
+        }
     }
-#pragma unroll
-    for (int p = 0; p < TG_PER_WG; ++p) {  // one workgroup reduction per position (np is uniform across the workgroup)
-        if (p >= np) break;
-        rv[threadIdx.x] = best[p];
-        ri[threadIdx.x] = bi[p];
-        __syncthreads();
-        for (int sft = 128; sft > 0; sft >>= 1) {
-            if ((int)threadIdx.x < sft) {
-                const double o = rv[threadIdx.x + sft];
-                const int oi = ri[threadIdx.x + sft];
-                if (o > rv[threadIdx.x] || (o == rv[threadIdx.x] && oi < ri[threadIdx.x])) { rv[threadIdx.x] = o; ri[threadIdx.x] = oi; }
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            int64_t* dst = ids + (size_t)pb[p] * L + pt[p];
-            if (*dst != ri[0]) atomicAdd(gstat + 1, 1);  // positions whose id the refinement changed
-            *dst = ri[0];
+    rv[threadIdx.x] = best;
+    ri[threadIdx.x] = bi;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) {
+            const double o = rv[threadIdx.x + sft];
+            const int oi = ri[threadIdx.x + sft];
+            if (o > rv[threadIdx.x] || (o == rv[threadIdx.x] && oi < ri[threadIdx.x])) { rv[threadIdx.x] = o; ri[threadIdx.x] = oi; }
         }
         __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (ids[(size_t)b * L + t] != ri[0]) atomicAdd(gstat + 1, 1);  // positions whose id the refinement changed
+        ids[(size_t)b * L + t] = ri[0];
     }
 }
 

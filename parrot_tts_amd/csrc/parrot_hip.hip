@@ -558,10 +558,10 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
         split16_tile(variant16, t.bm, t.bn, c->kk);
         // conv_split16_kernel addresses the (M, Tout) output / residual tile of a batch row with 32-bit byte offsets (RowTile)
         if ((double)c->M * Tout * 4.0 >= 2147483648.0) return fail(PARROT_E_UNSUPPORTED, "conv_run: output row tile larger than 2 GiB");
-        {   // rows that start on 16-byte boundaries take the 16-byte epilogue (PARROT_EPI16=0: A/B switch of the round-4 change)
-            static const int epi16 = [] { const char* e = getenv("PARROT_EPI16"); return e ? atoi(e) : 1; }();
+        {   // rows that start on 16-byte boundaries take the 16-byte epilogue (round-4 A/B on one box, profiles/r04a_*: the dominant
+            // kernel 231.0 us per launch with it, 231.1 us without -- the C/D-layout stores were not what bounds the epilogue)
             auto al16 = [](const void* q, long stride) { return (reinterpret_cast<size_t>(q) & 15) == 0 && (stride & 3) == 0; };
-            p.epi16 = epi16 && (Tout % 4 == 0) && al16(y, p.y_bstride) && (!res || al16(res, p.res_bstride));
+            p.epi16 = (Tout % 4 == 0) && al16(y, p.y_bstride) && (!res || al16(res, p.res_bstride));
         }
     } else if (c->prec >= 1) {
         // 1x1 convs (Linear layers) have one MFMA step per barrier: the 128x64 / 3-waves-per-SIMD variant hides that
@@ -1728,8 +1728,7 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
             // earlier (conv2 + bias + residual in fp64, then the head); without a decoder block it starts at w.x
             const bool deep = t->last_w2t != nullptr && !t->dec.empty();
             const int F = c.n_filter_ffn;
-            hipLaunchKernelGGL(tie_guard_refine_kernel, dim3(TIE_GUARD_MAX / TG_PER_WG), dim3(256),
-                               (size_t)TG_PER_WG * (D + (deep ? F : 0)) * sizeof(double), s, w.x,
+            hipLaunchKernelGGL(tie_guard_refine_kernel, dim3(TIE_GUARD_MAX), dim3(256), (size_t)(D + (deep ? F : 0)) * sizeof(double), s, w.x,
                                t->head_w, t->head_b, ids, D, V, L, glist, gstat, deep ? w.f : nullptr, deep ? w.h : nullptr, t->last_w2t,
                                t->last_b2, F, gref, row0);
             HIP_TRY(hipGetLastError());

@@ -204,6 +204,7 @@ def test_tile_and_wave_grid_switches_do_not_change_a_bit():
 
     ref = hashes({})
     assert len(ref.strip().splitlines()) == 3
-    for env in ({"PARROT_S16_N160": "0", "PARROT_SPLIT_WN1": "0", "PARROT_S16_M64": "0"}, {"PARROT_SMALL_TILES": "0", "PARROT_S16_N160": "1"},
-                {"PARROT_S16_PRIO": "1", "PARROT_MRF_STREAMS": "3"}):
+    # (round 4 pruned the wave-grid / tile-width experiment switches; what is left that re-partitions outputs among workgroups or
+    #  streams: the small-tile rule, the MRF branch streams, the row groups / lanes of the TTE)
+    for env in ({"PARROT_SMALL_TILES": "0"}, {"PARROT_MRF_STREAMS": "3"}, {"PARROT_MRF_STREAMS": "1", "PARROT_TTE_LANES": "2"}):
         assert hashes(env) == ref, env

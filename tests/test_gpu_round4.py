@@ -308,3 +308,34 @@ def test_row_groups_keep_the_tie_guard_working(tmp_path):
     assert torch.equal(ids[mask], torch.argmax(ref["logits"], -1)[mask])
     lg, pos = pipe.parrot.guard_logits()
     assert lg.shape[0] == n_pos and sorted(set(int(b) for b in pos[:, 0])) == list(range(40))  # batch rows, not rows of a group
+
+
+def test_tte_lanes_leave_every_output_bit_unchanged(tmp_path, monkeypatch):
+    """parrot_tte_encode_rows / parrot_tte_decode_rows with the row groups of a batch encoding and decoding SIDE BY SIDE on two or
+    three streams (PARROT_TTE_LANES; per-lane tie-guard lists): log-durations, durations, ids, masks, logits and the guard
+    statistics equal the one-lane run's bit for bit on a ragged batch."""
+    import parrot_tts_amd.tte as tte_mod
+    outs = {}
+    for lanes in (1, 2, 3):
+        monkeypatch.setattr(tte_mod, "_TTE_LANES", lanes)
+        # (every position is a tie -> guarded; 50 rows x <= 4 positions stay below a lane's 256-entry list)
+        pipe, batch, _, _ = _pipeline_with(tmp_path, 50, 4, True, 5, 1, tie_head=True, forced_duration=1)
+        gb = {k: v.to(DEV) for k, v in batch.items()}
+        par = pipe.parrot
+        par.infer_dense(gb)  # first decode of the handle (range probe)
+        assert len(par._lanes(50)) == lanes
+        r = par._run(gb, want_logits=True)
+        par.check_outputs()
+        gs = par.guard_stats()
+        lg, pos = par.guard_logits()
+        order = sorted(range(pos.shape[0]), key=lambda i: (int(pos[i, 0]), int(pos[i, 1])))
+        outs[lanes] = {"ids": r["ids"].cpu(), "tgt": r["tgt_mask"].cpu(), "logits": r["logits"].cpu(), "log_dur": r["log_dur"].cpu(),
+                       "dur": r["dur"].cpu(), "lens": r["lens"].clone(), "n": gs["n_guarded"], "min": gs["min_margin"],
+                       "pos": pos[order], "lg": lg[order]}
+    ref = outs[1]
+    assert ref["n"] > 0
+    for lanes in (2, 3):
+        o = outs[lanes]
+        for k in ("ids", "tgt", "logits", "log_dur", "dur", "lens", "pos", "lg"):
+            assert torch.equal(o[k], ref[k]), (lanes, k)
+        assert o["n"] == ref["n"] and o["min"] == ref["min"]
