@@ -1,7 +1,7 @@
 """Does HIP-graph replay shorten the launch-bound parts at B = 1?  Times direct launches vs graph replay of parrot_tte_encode,
 parrot_tte_decode and the vocoder forward with fixed buffers."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from parrot_tts_amd import _lib, ops, synth
