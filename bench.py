@@ -199,7 +199,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run(precision, steps, warmup, overlap_steps=False, workload=None, B=B, tte_precision=None):
+    def run(precision, steps, warmup, overlap_steps=False, workload=None, B=B, tte_precision=None, profile=True):
         """Build both models under `precision`, then W untimed + K timed steps.  Returns (max-over-ranks seconds,
         per-kernel profile rows, samples per step over all ranks, model pieces for the CPU baseline)."""
         workload = workload or a.workload
@@ -256,22 +256,26 @@ def main():
         # around the dominant kernel's launches only -- `roofline.achieved` is measured there, live, as the contract asks -- because
         # a pair of event records around all ~130 launches of a step is itself 0.6 ms of a B = 64 step (3 %) and 0.4 ms of a 2 ms
         # single-utterance step: measurement overhead, not work of the path (tools/step_time.py --prof shows the A/B).
-        n_table = 2 if warmup >= 3 else 1
+        # (`profile=False`: no events at all -- latency rows such as the single utterance, whose ~130 launches take 7-40 us each)
+        n_table = (2 if warmup >= 3 else 1) if profile else 0
         wav = None
         for _ in range(max(warmup - n_table, 1 if warmup else 0)):
             wav = step()
         wav = drain() if overlap and warmup else wav
         fence()
-        lib.parrot_prof_begin()
-        for _ in range(n_table):
-            wav = step()
-        wav = drain() if overlap else wav
-        fence()
-        table = read_rows(n_table)
-        table.sort(key=lambda r: -r["ms_per_step"])
+        table = []
+        if profile:
+            lib.parrot_prof_begin()
+            for _ in range(n_table):
+                wav = step()
+            wav = drain() if overlap else wav
+            fence()
+            table = read_rows(n_table)
+            table.sort(key=lambda r: -r["ms_per_step"])
         dom_row = table[0]["row"] if table else 0
         gather_ev.clear()
-        _lib.check(lib.parrot_prof_begin_row(dom_row))
+        if profile:
+            _lib.check(lib.parrot_prof_begin_row(dom_row))
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
@@ -284,7 +288,7 @@ def main():
         in_use = {"tte": parrot.precision_in_use if workload == "full" else precision, "vocoder": gen.precision_in_use}
         if in_use["vocoder"] not in (None, precision) or in_use["tte"] not in (None, tte_precision or precision):
             raise SystemExit(f"bench.py: asked for precision {precision} but the handles ran as {in_use} (non-finite output -> fallback)")
-        timed = read_rows(steps)  # the dominant kernel's launches of the timed region
+        timed = read_rows(steps) if profile else []  # the dominant kernel's launches of the timed region
         g_ms = sum(a_.elapsed_time(b_) for a_, b_ in gather_ev) / max(steps, 1)
         t = torch.tensor([elapsed, g_ms], dtype=torch.float64, device=dev)
         if world > 1:
@@ -478,8 +482,8 @@ def main():
                         "workload": "HiFi-GAN generator only, batch 32 x %d units (BASELINE configs[1])" % (4 * S),
                         "dominant_kernel": rows3[0]["kernel"], "dominant_tflops": rows3[0]["tflops"]}
         # BASELINE.json configs[0] shape: ONE utterance end to end (latency-bound: ~130 launches)
-        e4, _, n4, _ = run(a.precision, a.steps, max(a.warmup, 3), B=1)
-        ms4 = e4 / a.steps * 1e3
+        e4, _, n4, _ = run(a.precision, max(a.steps, 50), max(a.warmup, 3), B=1, profile=False)
+        ms4 = e4 / max(a.steps, 50) * 1e3
         res["single_utterance_b1"] = {"value": n4 / (ms4 / 1e3), "unit": "samples/s", "ms_per_step": ms4, "rtf": (ms4 / 1e3) / (n4 / SAMPLE_RATE),
                                       "workload": "full pipeline, ONE utterance (S=%d -> %d units), BASELINE configs[0] shape" % (S, 4 * S)}
         # BASELINE.json configs[4]: long-form 30 s utterances, batch 8 x 1500 units, chunk-streamed vocoder (256-unit chunks)

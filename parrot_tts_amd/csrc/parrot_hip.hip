@@ -305,6 +305,12 @@ static bool mfma16_enabled() {
     static const bool on = [] { const char* e = getenv("PARROT_MFMA16"); return !e || atoi(e) != 0; }();
     return on;
 }
+// PARROT_SMALL_TILES: 2 (default) = 64-column tiles for underfilled launches and 64-row tiles for far-underfilled ones, 1 = the
+// 64-column tiles only, 0 = neither
+static int small_tiles_mode() {
+    static const int m = [] { const char* e = getenv("PARROT_SMALL_TILES"); return e ? atoi(e) : 2; }();
+    return m;
+}
 static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, const float* w, const float* bias, bool allow16 = true) {
     if (!out || !d || !w) return fail(PARROT_E_INVALID, "conv_create: null argument");
     if (d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->dilation <= 0 || groups <= 0 || d->c_in % groups || d->c_out % groups)
@@ -546,14 +552,20 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     }
     TileCfg t = tile_cfg(cfg);
     int variant16 = 0;
-    static const bool small_tiles = [] { const char* e = getenv("PARROT_SMALL_TILES"); return !e || atoi(e) != 0; }();
+    const bool small_tiles = small_tiles_mode() >= 1;
     if (c->mfma16) {
         variant16 = c->M >= 128 ? 0 : 1;
         split16_tile(variant16, t.bm, t.bn, c->kk);
         // small batches: a launch that would not give every CU a workgroup takes the 64-column tiles (2-3x the workgroups,
         // a half / third of the MFMAs per step: the per-launch latency is what counts there, not the operand reuse)
-        if (small_tiles && (long)((p.Ncols + t.bn - 1) / t.bn) * B * ((c->M + t.bm - 1) / t.bm) < g_num_cus) variant16 += 2;
-        else if (small_tiles && p.Ncols <= 64) variant16 += 2;  // sequences of <= 64 steps (the TTE encoder side) would leave half of a 128-column tile empty
+        if (small_tiles && (long)((p.Ncols + t.bn - 1) / t.bn) * B * ((c->M + t.bm - 1) / t.bm) < g_num_cus) {
+            variant16 += 2;
+            // ... and 64-row workgroups for the 128-row layers when even that leaves more than half of the CUs idle (one to four
+            // utterances): four waves per workgroup, one per SIMD, twice the workgroups -- single utterance 2.08 -> 2.00 ms, B = 4
+            // 2.63 -> 2.57 ms; 32-row workgroups (2 waves, four slab items per thread) measured slower (2.11 / 2.69 ms)
+            split16_tile(variant16, t.bm, t.bn, c->kk);
+            if (small_tiles_mode() >= 2 && (long)((p.Ncols + t.bn - 1) / t.bn) * B * ((c->M + t.bm - 1) / t.bm) * 2 <= g_num_cus && c->M >= 128) variant16 = 3;
+        } else if (small_tiles && p.Ncols <= 64) variant16 += 2;  // sequences of <= 64 steps (the TTE encoder side) would leave half of a 128-column tile empty
         else if (variant16 == 0 && split16_wide_fits(p.Ncols, B, (c->M + 127) / 128, g_num_cus)) variant16 = 4;  // 128 x 160: no half-empty last round
         split16_tile(variant16, t.bm, t.bn, c->kk);
         // conv_split16_kernel addresses the (M, Tout) output / residual tile of a batch row with 32-bit byte offsets (RowTile)
