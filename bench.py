@@ -45,7 +45,9 @@ TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>"
               "conv1_valu_kernel", "convt_valu_kernel<16,4,2,1>", "conv_split16_kernel<SCH,2,2,4,4>",
               "conv_split16_kernel<SCH,2,2,2,4>",  # the 64-row tile
               "(unused)", "conv_split16_kernel<SCH,2,2,4,5>",
-              "resblock_split_kernel<SCH,4>", "resblock_split_kernel<SCH,8>", "resblock_split_kernel<SCH,16>"]
+              "resblock_split_kernel<SCH,4>", "resblock_split_kernel<SCH,8>", "resblock_split_kernel<SCH,16>",
+              "resblock_split_kernel<SCH,2,8,MRF>", "resblock_split_kernel<SCH,4,4,MRF>",  # whole-MRF launches (32 / 64 channels)
+              "resblock16_split_kernel<SCH,MRF>"]
 SCHEMES = {"f16x3": ("SchF16x3", 3), "bf16x6": ("SchBf16x6", 6), "bf16": ("SchBf16", 1), "f16": ("SchF16", 1), "f32": ("-", 1)}
 MFMA16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split scheme spends 3 (f16x3) or 6 (bf16x6) MFMA FMAs per algorithmic fp32 FMA
 
@@ -170,9 +172,6 @@ def main():
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("PARROT_BENCH_OVERLAP", "0")),
                     help="1: the headline run itself uses the two-stage pipeline across steps (TTE of batch i on a side stream beside "
                          "the vocoder of batch i-1); default 0: one batch at a time, the pipelined rate is reported next to it")
-    ap.add_argument("--row-groups", type=int, default=None,
-                    help="row groups of the in-batch software pipeline (decoder of group g + 1 beside the vocoder of group g); "
-                         "default: SynthesisPipeline's (2, PARROT_ROW_GROUPS); 1 = the whole batch through one stage after the other")
     ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "bf16", "f16"], default=os.environ.get("PARROT_BENCH_PRECISION", "f16x3"),
                     help="product evaluation of the conv kernels for layers with >= 16 channels (fp32 data either way): f16x3 (default), "
                          "bf16x6 and f32 are parity-grade; bf16 / f16 are the single-MFMA reduced-precision operating point")
@@ -207,8 +206,7 @@ def main():
         cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
         if tte_precision is not None:  # (BASELINE configs[2]: fp32-class TTE in front of the reduced-precision vocoder)
             parrot._precision_override = ops.PREC_NAMES[tte_precision]
-        pipe = SynthesisPipeline(parrot, gen, row_groups=(None if a.row_groups is None else a.row_groups))
-        run.row_groups = [n for _, n in pipe._groups(B)]
+        pipe = SynthesisPipeline(parrot, gen)
         batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(B, S, vocab, n_spk, seed=rank).items()}
         vb = {k: v.to(dev) for k, v in synth.synth_voc_batch(B, 4 * S, h, seed=rank).items()}
 
@@ -396,7 +394,6 @@ def main():
         return out
 
     elapsed, rows, n_samples_step, pieces = run(a.precision, a.steps, a.warmup, overlap_steps=bool(a.overlap))
-    head_groups = list(run.row_groups)
     gather_ms = run.gather_ms
 
     if rank == 0:
@@ -458,11 +455,6 @@ def main():
         res["schedule"] = ("two-stage pipeline across steps: the TTE of batch i runs on a side HIP stream beside the vocoder of batch "
                            "i-1 (SynthesisPipeline.submit); every batch submitted inside the timed region is finished inside it"
                            if (a.overlap and a.workload == "full") else "one batch at a time")
-        if a.workload == "full" and not a.overlap and len(head_groups) > 1:
-            res["schedule"] += ("; inside a batch the TTE decoder of row group g + 1 runs on a side HIP stream beside the vocoder of row "
-                                "group g (groups of %s rows; encoder, durations and the expanded length are the whole batch's, "
-                                "results identical to the ungrouped run)" % "+".join(str(n) for n in head_groups))
-        res["config"]["row_groups"] = head_groups if a.workload == "full" else [B]
     if world == 1 and a.workload == "full" and not a.no_alt:
         # the same steps under the other schedule, for reference (kernel timings of the pipelined schedule include the
         # side stream's interference, so `roofline` is only clean with one batch at a time: the default headline)

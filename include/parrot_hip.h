@@ -6,7 +6,7 @@
  * the seam this library plugs into is the nn.Module surface the reference drivers call.  Each
  * entry point below names the reference code it replaces (paths relative to the reference
  * repo).  The Python shims in parrot_tts_amd/ (tte.py, vocoder.py) bind these with ctypes --
- * see INTEGRATION.md.
+ * see INTEGRATION.md.  Test / profiling / probe entry points live in parrot_hip_debug.h.
  *
  * Conventions
  *   - plain C types only; no torch / C++ types cross the boundary
@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PARROT_ABI_VERSION 5
+#define PARROT_ABI_VERSION 6
 
 enum {
     PARROT_OK = 0,
@@ -43,8 +43,6 @@ enum {
 
 int parrot_abi_version(void);
 const char* parrot_last_error(void);
-/* Runs the MFMA fragment-layout probe on the current device (0 = layouts as assumed). */
-int parrot_selftest(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Single Conv1d / ConvTranspose1d plan: the dilated-Conv1d implicit-GEMM kernel behind every
@@ -100,24 +98,6 @@ void parrot_conv_destroy(parrot_conv_t*);
 int parrot_conv_run(parrot_conv_t*, const float* x, const float* res, float* y, int32_t B, int32_t T_in,
                     int32_t epilogue, float div, void* stream);
 int parrot_conv_out_len(const parrot_conv_t*, int32_t T_in);
-int parrot_conv_num_tile_cfgs(void);
-
-/* Optional per-launch timing of the conv kernel with HIP events on the launch stream, aggregated
- * per tile configuration (bench.py's roofline object).  prof_end fills out[cfg*4 + {0..3}] =
- * {launches, total ms, algorithmic FLOPs, algorithmic bytes} for n_cfg configurations.         */
-/* dst[i] = src[i], 4 bytes per lane: known-byte-count kernel for calibrating the HBM PMC counters. */
-int parrot_debug_copy(const float* src, float* dst, size_t n, void* stream);
-/* Measurement aid (bench.py `roofline.ceiling_probe_tflops`): the rate a bare fp16 MFMA stream sustains on this device under
- * its power limit -- shape 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16; random operands (constant_data = 0) or one
- * constant (1); two waves per SIMD, ~20-40 ms.  Synchronises the device.  TFLOP/s of 16-bit MFMA work in *tflops_out. */
-int parrot_debug_mfma_ceiling(int32_t shape, int32_t constant_data, double* tflops_out);
-/* Per-launch timing of the conv kernels (HIP events on the launch stream, aggregated per kernel row: bench.py's roofline
- * object).  parrot_prof_begin times every launch; parrot_prof_begin_row only the launches of one row (the dominant kernel):
- * event records around every launch of a step are themselves 3 % of a B = 64 step and 20 % of a single-utterance one.
- * parrot_prof_end: out[4 row + {0,1,2,3}] = {launches, total ms, algorithmic flops, algorithmic bytes}. */
-int parrot_prof_begin(void);
-int parrot_prof_begin_row(int32_t row);
-int parrot_prof_end(double* out, int32_t n_cfg);
 
 /* ------------------------------------------------------------------------------------------
  * HiFi-GAN unit vocoder: CodeGenerator.forward (utils/vocoder/models.py:153-169) ->
@@ -169,11 +149,6 @@ int parrot_voc_create_ex(parrot_voc_t** out, const parrot_voc_cfg* cfg, const pa
 void parrot_voc_destroy(parrot_voc_t*);
 /* PARROT_PREC_* this handle was created with (the "precision in use" after a fallback). */
 int parrot_voc_precision(const parrot_voc_t*);
-/* Debug aid: headroom to the fp16 split scheme's range.  While dst_dev != NULL every conv launched by parrot_voc_forward records
- * max |input element| into dst_dev[group] (device floats, atomic max; the caller zeroes them): group 0 = conv_pre, 1 + i = the
- * layers of stage i (ups_i, its ResBlock convs), n_stages + 1 = conv_post.  Fused ResBlock launches only see their block's input:
- * create the handle with fused_resblocks = 0 to cover every layer.  NULL switches it off. */
-int parrot_voc_debug_absmax(parrot_voc_t*, float* dst_dev);
 size_t parrot_voc_workspace_bytes(const parrot_voc_t*, int32_t B, int32_t U);
 /* code (B,U) int64, spkr (B,1) int64 or NULL -> wav (B,1,U*prod(rates)) fp32 in (-1,1).
  * unit_lens: optional (B) int32 device array of real units per row (ragged batch padded to U): every layer applies its
@@ -262,35 +237,24 @@ int parrot_tte_precision(const parrot_tte_t*);
 size_t parrot_tte_state_bytes(const parrot_tte_t*, int32_t B, int32_t S);
 size_t parrot_tte_workspace_bytes(const parrot_tte_t*, int32_t B, int32_t S, int32_t L_max);
 /* Phase 1 (parrot.py:94-102 up to the durations): phones (B,S) i64, src_mask (B,S) u8 1=valid,
- * speaker (B) i64 or NULL -> log_dur (B,S) f32, dur (B,S) i64, out_lens (B) i32 (sum of dur). */
+ * speaker (B) i64 or NULL -> log_dur (B,S) f32, dur (B,S) i64, out_lens (B) i32 (sum of dur).
+ * src_len: NULL = the reference's PADDED-BATCH semantics (Parrot.forward on the padded batch: pe[S] of the padded length,
+ *   pad frames leak through the k = 9 / k = 3 convs -- quirk Q7: a row's result depends on the batch it is padded into).
+ *   (B) i32 device = ROW-EXACT mode: row b holds src_len[b] real tokens (src_mask must be that prefix) and is evaluated as the
+ *   reference evaluates that utterance ALONE (its drivers run batch_size = 1, inference.py:34): pe[src_len[b]] (fft.py:18), every
+ *   conv zero-padded at the row's own end (fft.py:78-82, duration.py:64-72), keys beyond it masked.                          */
 int parrot_tte_encode(parrot_tte_t*, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker,
-                      int32_t B, int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens,
+                      const int32_t* src_len /* nullable */, int32_t B, int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens,
                       void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
 /* Phase 2 (duration.py:6-24, parrot.py:106-108,115): needs L = max(out_lens) from the host
  * (the reference's own host sync, duration.py:10).  -> ids (B,L) i64 argmax, tgt_mask (B,L) u8
- * (ids <= len, quirk Q2), optional logits (B,L,n_codes) f32 (tests).                          */
-int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L,
+ * (ids <= len, quirk Q2), optional logits (B,L,n_codes) f32 (tests).
+ * row_exact != 0 (after an encode with src_len): row b is decoded as its own B = 1 run -- pe[out_lens[b]] (parrot.py:106), convs
+ * zero-padded and keys masked at out_lens[b]; tgt_mask[b] = t < max(out_lens[b], 1): the row's ids are ids[b, :out_lens[b]]
+ * (alone, a row is the longest of its batch and emits exactly its length -- no extra frame).                                */
+int parrot_tte_decode(parrot_tte_t*, int32_t B, int32_t S, int32_t L, int32_t row_exact,
                       int64_t* ids, uint8_t* tgt_mask, float* logits /* nullable */,
                       void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
-/* Row groups.  Every encoder / decoder kernel works row by row, pe[S] / pe[L] are indexed by the padded length S and by the WHOLE
- * batch's L = max(out_lens) whichever rows run (fft.py:18, parrot.py:106), so the batch can be cut into row groups that run
- * one after the other or CONCURRENTLY on several streams ("lanes": the TTE's launches are small, two lanes fill the chip better)
- * with results identical, bit for bit, to parrot_tte_encode / parrot_tte_decode on the whole batch.
- * parrot_tte_encode_rows: phase 1 for rows [row0, row0 + n_rows) of a batch of B rows; every pointer argument is the group's own
- *   first row, `state` is the whole batch's (B rows), ws needs workspace_bytes(n_rows, S, 0).
- * parrot_tte_decode_rows: phase 2 for such a group; ids / tgt_mask / logits point at the group's first row, ws needs
- *   workspace_bytes(n_rows, S, L).  `lane` (0..3) selects the tie-guard list the group's low-margin positions go to: groups that
- *   decode concurrently use different lanes, groups of one lane run in order on one stream.  flags: PARROT_ROWS_GUARD_RESTART on a
- *   lane's first group of a batch, PARROT_ROWS_NEW_BATCH additionally on the batch's very first call (it resets which lanes the
- *   guard statistics readers add up). */
-#define PARROT_ROWS_GUARD_RESTART 1
-#define PARROT_ROWS_NEW_BATCH 2
-int parrot_tte_encode_rows(parrot_tte_t*, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker,
-                           int32_t B, int32_t S, int32_t row0, int32_t n_rows, float* log_dur, int64_t* dur, int32_t* out_lens,
-                           void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
-int parrot_tte_decode_rows(parrot_tte_t*, int32_t B, int32_t S, int32_t L, int32_t row0, int32_t n_rows, int32_t lane, int32_t flags,
-                           int64_t* ids, uint8_t* tgt_mask, float* logits /* nullable */,
-                           void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
 /* Device-side flags.  Synchronises `stream`, clears the flag; returns 0, PARROT_E_RANGE (a bad phone / speaker id <-> the
  * reference's Embedding IndexError) or PARROT_E_NONFINITE (NaN / inf logits at some position of the last decode: an
  * activation beyond the fp16 split scheme's range -- the ids of that call are not to be trusted). */
@@ -311,12 +275,6 @@ int parrot_tte_guard_logits(parrot_tte_t*, float* logits_dev, int32_t* list_dev,
 /* The same flag without a synchronisation (3 / 4 bad phone / speaker id, 5 non-finite logits): see parrot_voc_status_async. */
 int parrot_tte_status_async(parrot_tte_t*, int32_t* dst_dev, void* stream);
 int parrot_tte_status_peek_async(parrot_tte_t*, int32_t* dst_dev, void* stream);
-/* Tests / error localisation: while set, the next encode / decode calls copy the channel-first (B, D, T) activation
- * after each stage to the given DEVICE buffers (NULL entries are skipped): enc_ptrs[0] = embedding + pe[S],
- * enc_ptrs[1 + n] = encoder block n, enc_ptrs[1 + enc_layers] = encoder output (+ speaker); dec_ptrs[0] = length
- * regulator output + pe[L], dec_ptrs[1 + n] = decoder block n.  Pass NULL, NULL to switch it off. */
-int parrot_tte_debug_stages(parrot_tte_t*, float* const* enc_ptrs, float* const* dec_ptrs);
-
 /* length_regulator alone (modules/duration.py:6-24 + modules/data.py:8-20), on the kernel the decoder uses:
  * seq (B,S,D) f32 as the reference holds it, dur (B,S) i64 -> out (B,L,D) (rows repeat_interleave'd, zero right-padded),
  * mask (B,L) u8 = ids <= len (quirk Q2), out_lens (B) i32.  L = max over rows of sum(dur), computed by the caller like

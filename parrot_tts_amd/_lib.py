@@ -1,4 +1,4 @@
-"""ctypes binding of libparrot_hip.so (include/parrot_hip.h).  Fails loudly when the HIP library
+"""ctypes binding of libparrot_hip.so (include/parrot_hip.h; test / profiling entry points: include/parrot_hip_debug.h).  Fails loudly when the HIP library
 is missing or does not load: there is NO CPU / eager fallback in this package."""
 from __future__ import annotations
 
@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARROT_HIP_LIB") or os.path.join(HERE, "libparrot_hip.so")
 
 MAX_STAGES, MAX_KERNELS, MAX_DIL = 8, 4, 4
+ABI_VERSION = 6  # PARROT_ABI_VERSION of include/parrot_hip.h
 c_float_p = C.POINTER(C.c_float)
 
 
@@ -61,7 +62,7 @@ class TteWeights(C.Structure):
                 ("head_w", c_float_p), ("head_b", c_float_p)]
 
 
-# name -> (restype, argtypes); every symbol include/parrot_hip.h declares
+# name -> (restype, argtypes); every symbol include/parrot_hip.h and include/parrot_hip_debug.h declare
 vp, i32, sz, f32 = C.c_void_p, C.c_int32, C.c_size_t, C.c_float
 SIGNATURES = {
     "parrot_abi_version": (C.c_int, []),
@@ -103,10 +104,8 @@ SIGNATURES = {
     "parrot_tte_guard_logits": (C.c_int, [vp, vp, vp, i32, vp]),
     "parrot_tte_state_bytes": (sz, [vp, i32, i32]),
     "parrot_tte_workspace_bytes": (sz, [vp, i32, i32, i32]),
-    "parrot_tte_encode": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
-    "parrot_tte_decode": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
-    "parrot_tte_encode_rows": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
-    "parrot_tte_decode_rows": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
+    "parrot_tte_encode": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
+    "parrot_tte_decode": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "parrot_tte_check": (C.c_int, [vp, vp]),
     "parrot_tte_status_async": (C.c_int, [vp, vp, vp]),
     "parrot_tte_status_peek_async": (C.c_int, [vp, vp, vp]),
@@ -134,7 +133,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.parrot_abi_version() != 5:
+        if handle.parrot_abi_version() != ABI_VERSION:
             raise ImportError("libparrot_hip.so ABI version mismatch")
         _lib = handle
     return _lib

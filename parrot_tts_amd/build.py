@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libparrot_hip.so")
 OBJ = os.path.join(HERE, "build")
 SOURCES = ["parrot_hip.hip"] + sorted(f for f in os.listdir(CSRC) if f.startswith("tu_") and f.endswith(".hip"))
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "parrot_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", h) for h in ("parrot_hip.h", "parrot_hip_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Per-source flags.  tu_split16: LLVM's machine-sink pass moves the weight refills for the next chunk's first k-step -- which feed
 # nothing but loop-carried registers -- out of the MFMA block into the loop latch, behind the slab conversion and the barrier, so

@@ -26,9 +26,9 @@ class LitParrot(nn.Module):
         self.hparams = AttrDict(data_config=data_config, src_vocab_size=src_vocab_size, src_pad_idx=src_pad_idx)
         self.parrot = Parrot(data_config, src_vocab_size, src_pad_idx)
 
-    def infer(self, batch):
+    def infer(self, batch, row_exact: bool = False):
         self.eval()
-        return self.parrot.infer(batch)
+        return self.parrot.infer(batch, row_exact=row_exact)
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location="cpu", weights_only: bool = True, **overrides):

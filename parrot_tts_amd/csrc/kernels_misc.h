@@ -45,12 +45,14 @@ static __global__ __launch_bounds__(256) void voc_embed_kernel(const int64_t* __
 
 // ---------------------------------------------------------------------------------------------
 // TTE input: x[b, c, s] = tok_emb[phones[b,s]][c] + pe[S][c]   (parrot.py:94-95, fft.py:17-19, Q1)
+// row_len (nullable): row-exact mode, pe[row_len[b]] -- the single row the reference adds when it runs that utterance alone.
 // ---------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void tte_embed_kernel(const int64_t* __restrict__ phones, const float* __restrict__ emb,
-                                                        const float* __restrict__ pe_row, float* __restrict__ x, int S, int D,
-                                                        int vocab, int* __restrict__ err) {
+                                                        const float* __restrict__ pe, const int32_t* __restrict__ row_len,
+                                                        float* __restrict__ x, int S, int D, int vocab, int* __restrict__ err) {
     __shared__ float tile[64][65];
     const int s0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const float* __restrict__ pe_row = pe + (size_t)(row_len ? min(max(row_len[b], 0), S) : S) * D;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) {
         const int s = s0 + r, c = c0 + tx;
@@ -291,9 +293,9 @@ constexpr int TIE_GUARD_MAX = 256;  // guarded positions per batch (argmax_cf_ke
 // reused over channels.
 // ---------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ enc, const int32_t* __restrict__ cum,
-                                                              const int32_t* __restrict__ out_len, const float* __restrict__ pe_row,
+                                                              const int32_t* __restrict__ out_len, const float* __restrict__ pe,
                                                               float* __restrict__ y, uint8_t* __restrict__ tgt_mask, int S, int L, int D,
-                                                              int* __restrict__ gstat = nullptr, int gstat_reset = 1) {
+                                                              int* __restrict__ gstat = nullptr, int gstat_reset = 1, int row_exact = 0, int pe_stride = -1) {
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6;  // lane = frame, the four waves split the channels
     const int t = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -305,7 +307,10 @@ static __global__ __launch_bounds__(256) void length_regulate_kernel(const float
     }
     if (t >= L) return;
     const int len = out_len[b];
-    if (wave == 0) tgt_mask[(size_t)b * L + t] = (t <= len) ? 1 : 0;
+    // padded batch: pe[L] of the batch-max length and the `<=` mask (one extra frame per shorter row, quirk Q2); row-exact: what the
+    // row's own B = 1 run sees -- pe[len] and exactly len frames (get_mask_from_lengths(len, max_len = len) is all True)
+    const float* __restrict__ pe_row = pe + (size_t)(row_exact ? min(len, L) : L) * (pe_stride < 0 ? D : pe_stride);  // (pe_stride 0: one row for every length)
+    if (wave == 0) tgt_mask[(size_t)b * L + t] = (row_exact ? t < len : t <= len) ? 1 : 0;
     int src = -1;
     if (t < len) {
         const int32_t* cb = cum + (size_t)b * S;

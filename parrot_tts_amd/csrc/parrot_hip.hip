@@ -1,6 +1,6 @@
 // parrot_hip.hip -- C ABI + host orchestration of the MI355X Parrot-TTS synthesis path.
 // See include/parrot_hip.h for the contract and the reference lines each entry point replaces.
-#include "../../include/parrot_hip.h"
+#include "../../include/parrot_hip_debug.h"  // (parrot_hip.h + the test / profiling entry points)
 
 #include <hip/hip_runtime.h>
 
@@ -311,6 +311,22 @@ static int small_tiles_mode() {
     static const int m = [] { const char* e = getenv("PARROT_SMALL_TILES"); return e ? atoi(e) : 2; }();
     return m;
 }
+// Per-handle modes (parrot_*_create_ex) reach the plan builders through a THREAD-LOCAL scope, never through the process
+// defaults: a create on one thread cannot leak its precision / fusion / merge mode into a parrot_conv_create or another
+// *_create running on a second thread, and a concurrent parrot_set_* is neither seen half-way nor reverted afterwards.
+static thread_local int tl_prec = -1, tl_fused = -1, tl_merge = -1;
+struct CreateScope {
+    int p0, f0, m0;
+    CreateScope(int prec, int fused, int merge) : p0(tl_prec), f0(tl_fused), m0(tl_merge) {
+        if (prec >= 0) tl_prec = prec;
+        if (fused >= 0) tl_fused = fused;
+        if (merge >= 0) tl_merge = merge ? 1 : 0;
+    }
+    ~CreateScope() { tl_prec = p0; tl_fused = f0; tl_merge = m0; }
+};
+static int create_prec() { return tl_prec >= 0 ? tl_prec : default_prec(); }
+static int create_fused() { return tl_fused >= 0 ? tl_fused : fused_mode(); }
+
 static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, const float* w, const float* bias, bool allow16 = true) {
     if (!out || !d || !w) return fail(PARROT_E_INVALID, "conv_create: null argument");
     if (d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->dilation <= 0 || groups <= 0 || d->c_in % groups || d->c_out % groups)
@@ -409,7 +425,7 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
         }
         return w[((size_t)m * Cing + i) * k + j];
     };
-    const int want_prec = (d->precision >= 0) ? d->precision : default_prec();
+    const int want_prec = (d->precision >= 0) ? d->precision : create_prec();
     if (want_prec > PARROT_PREC_F16) return fail(PARROT_E_INVALID, "conv_create: unknown precision");
     // split kernels: at 32 rows the exact kernel is as fast (measured); the slab fetch needs whole 16-channel chunks
     // and evaluates the leaky ReLU as max(v, slope * v).  Everything else runs on the exact kernel (same results class).
@@ -653,6 +669,12 @@ struct parrot_voc {
     std::vector<uint16_t*> rb_stream;  // per (stage, kernel): concatenated split weight stream of the block (or null)
     std::vector<float> rb_wsc;         // per resblock conv: weight scale inside that stream (fp16 schemes; else 1)
     std::vector<size_t> rb_conv_halves;  // 16-bit words per conv in that stream
+    // whole-MRF launches (resblock_split.h, MRF instantiations): per (stage, kernel) the branch's stream in the 32x32x16 layout --
+    // rb_stream's where it exists, else packed for this path (64 channels, k = 11: its layer plans are packed for conv_split16);
+    // mrf_ok[stage]: every branch of the stage has one and the window survives the widest branch's reach
+    std::vector<uint16_t*> mrf_stream;
+    std::vector<uint16_t*> mrf_owned;
+    std::vector<char> mrf_ok;
     int up_total = 1;
     bool odd_stage = false;            // some stage has odd kernel_size - rate: T_out = T u + 1 there (no constant hop)
     int scheme = 0;                    // PARROT_PREC_* captured at create (immutable afterwards)
@@ -686,6 +708,8 @@ struct parrot_voc {
         if (ev_lane_fork) (void)hipEventDestroy(ev_lane_fork);
         for (hipEvent_t e : ev_lane_join)
             if (e) (void)hipEventDestroy(e);
+        for (uint16_t* q : mrf_owned)
+            if (q) (void)hipFree(q);
         for (uint16_t* q : rb_stream)
             if (q) (void)hipFree(q);
         if (dict) (void)hipFree(dict);
@@ -721,19 +745,10 @@ extern "C" int parrot_voc_create_ex(parrot_voc_t** out, const parrot_voc_cfg* cf
     if (precision > PARROT_PREC_F16 || fused_resblocks > 2) return fail(PARROT_E_INVALID, "voc_create_ex: precision in -1 .. 4, fused_resblocks in -1 .. 2");
     return voc_create_impl(out, cfg, w, precision, fused_resblocks);
 }
-// (the conv plans read the precision from the process default at build time: the per-handle value is installed around the
-//  build under a mutex, so concurrent creates with different precisions do not see each other's)
-static std::mutex g_create_mu;
 static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w);
 static int voc_create_impl(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w, int prec, int fused) {
-    std::lock_guard<std::mutex> lk(g_create_mu);
-    const int prec0 = default_prec(), fused0 = fused_mode();
-    if (prec >= 0) g_default_prec.store(prec);
-    if (fused >= 0) g_fused.store(fused);
-    const int r = voc_create_body(out, cfg, w);
-    g_default_prec.store(prec0);
-    g_fused.store(fused0);
-    return r;
+    CreateScope scope(prec, fused, -1);  // (thread-local: the process defaults are not touched)
+    return voc_create_body(out, cfg, w);
 }
 static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const parrot_voc_weights* w) {
     if (!out || !cfg || !w) return fail(PARROT_E_INVALID, "voc_create: null argument");
@@ -749,8 +764,8 @@ static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const 
     std::unique_ptr<parrot_voc> v(new parrot_voc());
     v->cfg = *cfg;
     query_device();
-    v->scheme = default_prec();
-    v->fused = fused_mode();
+    v->scheme = create_prec();
+    v->fused = create_fused();
     {
         const char* e = getenv("PARROT_MRF_STREAMS");
         // default "auto": concurrent branches for small batches (B = 1 ... 16: -6 ... -11 % per batch: their launches do not
@@ -871,6 +886,58 @@ static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const 
                 HIP_TRY(hipMemcpy(st, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             }
         }
+    // whole-MRF launches for the 32- and 64-channel stages (PARROT_MRF_FUSED, default on): all branches of a stage in one kernel
+    v->mrf_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
+    v->mrf_ok.assign((size_t)cfg->n_stages, 0);
+    {
+        static const bool want = [] { const char* e = getenv("PARROT_MRF_FUSED"); return !e || atoi(e) != 0; }();
+        for (int i = 0; i < cfg->n_stages && want && v->fused != 0 && v->scheme >= 1 && resblock_mrf_scheme(v->scheme); ++i) {
+            const int C = v->chan(i);
+            if (cfg->resblock_type != 1 || !resblock_mrf_has(C) || per_rb > RBS_MAX_CONVS || cfg->n_kernels > RBS_MAX_BRANCH) continue;
+            bool ok = true;
+            int Hmax = 0;
+            for (int j = 0; j < cfg->n_kernels && ok; ++j) {
+                const int rk = cfg->resblock_kernel_sizes[j];
+                const int base = (i * cfg->n_kernels + j) * per_rb;
+                if (!(rk & 1)) { ok = false; break; }
+                int H = 0;
+                for (int q = 0; q < per_rb; ++q) H += (rk - 1) / 2 * v->rb[base + q]->dil;
+                Hmax = std::max(Hmax, H);
+                if (v->rb_stream[(size_t)i * cfg->n_kernels + j]) {
+                    v->mrf_stream[(size_t)i * cfg->n_kernels + j] = v->rb_stream[(size_t)i * cfg->n_kernels + j];
+                    continue;
+                }
+                // pack [conv][32-row tile][chunk * k + tap][piece][lane][8 x 16 bit] (+ one conv of padding for the prefetch past the end)
+                const int steps = (C / 32) * (C / 16) * rk;
+                const size_t step_h = (size_t)NP * 512;
+                std::vector<uint16_t> pk(((size_t)(per_rb + 1) * steps) * step_h, 0);
+                for (int q = 0; q <= per_rb; ++q) {
+                    const int qq = q < per_rb ? q : 0;
+                    const float* wq = w->rb_w[base + qq];  // (C, C, rk)
+                    const float wsc = scheme_is_f16(v->scheme) ? f16_weight_scale(wq, (size_t)C * C * rk) : 1.f;
+                    if (q < per_rb) v->rb_wsc[base + q] = wsc;
+                    for (int mt = 0; mt < C / 32; ++mt)
+                        for (int ch = 0; ch < C / 16; ++ch)
+                            for (int tap = 0; tap < rk; ++tap) {
+                                uint16_t* g = pk.data() + ((size_t)q * steps + (size_t)mt * (C / 16) * rk + (size_t)ch * rk + tap) * step_h;
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int e = 0; e < 8; ++e) {
+                                        const int row = mt * 32 + (lane & 31), cin = ch * 16 + 8 * (lane >> 5) + e;
+                                        uint16_t hh[3];
+                                        split_weight(wq[((size_t)row * C + cin) * rk + tap], v->scheme, wsc, hh);
+                                        for (int pc = 0; pc < NP; ++pc) g[pc * 512 + lane * 8 + e] = hh[pc];
+                                    }
+                            }
+                }
+                uint16_t* st = nullptr;
+                HIP_TRY(hipMalloc((void**)&st, pk.size() * sizeof(uint16_t)));
+                v->mrf_owned.push_back(st);
+                HIP_TRY(hipMemcpy(st, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                v->mrf_stream[(size_t)i * cfg->n_kernels + j] = st;
+            }
+            v->mrf_ok[i] = ok && rbs_mrf_window(C) - 2 * Hmax >= rbs_mrf_window(C) / 2;
+        }
+    }
     // final F.leaky_relu(x) uses the DEFAULT slope 0.01 (models.py:107, quirk Q5)
     TRY(make_conv(v->conv_post, C0 >> cfg->n_stages, 1, 7, 1, 3, 0, 1, PRE_LRELU, 0.01f, ACT_TANH, w->conv_post_w, w->conv_post_b));
     v->conv_post->err_flag = v->err;  // a non-finite waveform sample (an activation left the fp16 split range) raises the handle's flag
@@ -1017,6 +1084,45 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         m0 = m1;
         ++n_launch;
     }
+    return PARROT_OK;
+}
+
+// Whole-MRF launch of a 32- / 64-channel stage (resblock_split.h, MRF instantiations): y = sum_j ResBlock_j(x) / n_kernels.
+static int mrf_split_launch(const parrot_voc* v, int stage, const float* x, float* y, int B, int T, hipStream_t s, const int32_t* row_len,
+                            int row_len_mul, int row_len_add) {
+    const parrot_voc_cfg& c = v->cfg;
+    const int per_rb = 2 * c.n_dil, C = v->chan(stage), nk = c.n_kernels;
+    const int W = rbs_mrf_window(C);
+    ResblockSplitParams p{};
+    p.x = x; p.y = y;
+    p.n_conv = per_rb; p.n_branch = nk;
+    int Hmax = 0;
+    double macs = 0;
+    for (int j = 0; j < nk; ++j) {
+        const int base = (stage * nk + j) * per_rb, k = c.resblock_kernel_sizes[j];
+        p.bstream[j] = v->mrf_stream[(size_t)stage * nk + j];
+        p.bk[j] = k;
+        int H = 0;
+        for (int q = 0; q < per_rb; ++q) {
+            p.bias[j * per_rb + q] = v->rb[base + q]->bias;
+            p.wsc[j * per_rb + q] = v->rb_wsc[base + q];
+            p.dil[j * per_rb + q] = v->rb[base + q]->dil;
+            H += (k - 1) / 2 * v->rb[base + q]->dil;
+        }
+        Hmax = std::max(Hmax, H);
+        macs += (double)B * C * C * k * T * per_rb;
+    }
+    p.k = p.bk[0];
+    p.T = T; p.B = B; p.H = Hmax;
+    p.TT = W - 2 * Hmax;
+    p.tiles = (T + p.TT - 1) / p.TT;
+    p.epi = nk > 1 ? EPI_ADD_DIV : EPI_STORE;
+    p.div = (float)nk; p.slope = 0.1f;
+    p.row_len = row_len; p.row_len_mul = row_len_mul; p.row_len_add = row_len_add;
+    ProfRec rec{};
+    if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 32 ? 16 : 17), 2.0 * macs, 4.0 * B * (double)C * T * 2, s));
+    HIP_TRY(launch_mrf_split(v->scheme, C, p, s));
+    if (g_prof_on) TRY(prof_close(rec, s));
     return PARROT_OK;
 }
 
@@ -1237,6 +1343,13 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         add = add * c.upsample_rates[i] + ((c.upsample_kernel_sizes[i] - c.upsample_rates[i]) & 1);  // out_len(n mul + add)
         const size_t n_act = (size_t)B * v->chan(i) * T;
         TRY(snap(1 + 2 * i, X, n_act));
+        if (v->mrf_ok[i] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {  // every branch of the stage in ONE launch
+            TRY(amax(1 + i, X, n_act, s));
+            TRY(mrf_split_launch(v, i, X, XS, B, T, s, unit_lens, mul, add));
+            TRY(snap(2 + 2 * i, XS, n_act));
+            ia = (ia + 2) % 3;
+            continue;
+        }
         if (ns > 1) {  // fork: the side streams see the upsampled stage input
             HIP_TRY(hipEventRecord(ss.ev_fork, s));
             for (int j = 1; j < ns; ++j) HIP_TRY(hipStreamWaitEvent(ss.side[j], ss.ev_fork, 0));
@@ -1327,7 +1440,7 @@ struct parrot_tte {
     float *head_w = nullptr, *head_b = nullptr;
     // (one set per decoder lane -- parrot_tte_decode_rows: row groups of one batch may decode concurrently on several streams --
     //  laid out back to back: lane l's list / statistics / refined logits start at l x the per-lane size)
-    static constexpr int LANES = 4;
+    static constexpr int LANES = 1;
     int *glist = nullptr, *gstat = nullptr;
     int lanes_used = 1;  // bit l: lane l took part in the last decoded batch (host-side bookkeeping of the statistics readers)
     float guard = 1e-4f;
@@ -1372,7 +1485,7 @@ static int build_fft(std::unique_ptr<FftLayer>& slot, const parrot_tte_cfg& c, i
     // nothing in between are ONE linear map: the products are formed here in fp64 and rounded once to fp32
     //     W_qkv' = blockdiag(W_in_q, W_in_k, W_in_v) * W_qkv   (3D x D),     W_o' = W_wo * W_out   (D x D)
     // which removes two launches per block (PARROT_TTE_MERGE=0 keeps the four separate projections).
-    const bool merge = tte_merge_default() != 0;
+    const bool merge = (tl_merge >= 0 ? tl_merge : tte_merge_default()) != 0;
     L->merged = merge;
     if (merge) {
         std::vector<float> wq((size_t)3 * D * D), wo((size_t)D * D);
@@ -1421,14 +1534,8 @@ static int build_fft(std::unique_ptr<FftLayer>& slot, const parrot_tte_cfg& c, i
 
 static int tte_create_body(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w);
 static int tte_create_impl(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w, int prec, int merge) {
-    std::lock_guard<std::mutex> lk(g_create_mu);
-    const int prec0 = default_prec(), merge0 = tte_merge_default();
-    if (prec >= 0) g_default_prec.store(prec);
-    if (merge >= 0) g_tte_merge.store(merge ? 1 : 0);
-    const int r = tte_create_body(out, cfg, w);
-    g_default_prec.store(prec0);
-    g_tte_merge.store(merge0);
-    return r;
+    CreateScope scope(prec, -1, merge);  // (thread-local: the process defaults are not touched)
+    return tte_create_body(out, cfg, w);
 }
 extern "C" int parrot_tte_create(parrot_tte_t** out, const parrot_tte_cfg* cfg, const parrot_tte_weights* w) {
     return tte_create_impl(out, cfg, w, -1, -1);
@@ -1449,7 +1556,7 @@ static int tte_create_body(parrot_tte_t** out, const parrot_tte_cfg* cfg, const 
     if (c.dp_kernel != 3) return fail(PARROT_E_UNSUPPORTED, "tte_create: duration_predictor.kernel_size != 3 changes the sequence length in the reference (padding=1 is hard-coded, duration.py:34)");
     std::unique_ptr<parrot_tte> t(new parrot_tte());
     t->cfg = c;
-    t->scheme = default_prec();
+    t->scheme = create_prec();
     {
         // flash attention runs on the fp16 split pipe: the default scheme and the fp16 reduced-precision mode take it; the exact
         // (f32), bf16x6 and bf16 handles keep the fp32-MFMA cores (fused for T <= 256, three kernels beyond)
@@ -1475,7 +1582,7 @@ static int tte_create_body(parrot_tte_t** out, const parrot_tte_cfg* cfg, const 
     TRY(upload(&t->ln0_b, w->dp_ln0_b, c.dp_filter));
     TRY(upload(&t->ln1_w, w->dp_ln1_w, c.dp_filter));
     TRY(upload(&t->ln1_b, w->dp_ln1_b, c.dp_filter));
-    t->merged = tte_merge_default() != 0;
+    t->merged = (tl_merge >= 0 ? tl_merge : tte_merge_default()) != 0;
     t->enc.resize(c.enc_layers);
     t->dec.resize(c.dec_layers);
     for (int i = 0; i < c.enc_layers; ++i) TRY(build_fft(t->enc[i], c, c.enc_heads, w->enc[i]));
@@ -1564,7 +1671,11 @@ static int layernorm(const float* x, const float* g, const float* b, float* y, i
 }
 
 // FFTBlock.forward (fft.py:94-100): x -> out (may alias x).  valid (B,T) u8: 1 = attend to this key.
-static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, float* x, const uint8_t* valid, int B, int T, hipStream_t s) {
+// row_len (B) i32 device, nullable: ROW-EXACT mode -- row b holds row_len[b] real positions and every conv applies its zero padding
+// at the row's own end (the reference run of that utterance alone, fft.py:78-82); NULL: the reference's padded-batch semantics, pad
+// frames leak through the k = 9 conv (quirk Q7).
+static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, float* x, const uint8_t* valid, int B, int T, hipStream_t s,
+                     const int32_t* row_len = nullptr) {
     const int D = t->cfg.d_model, H = L->heads, hd = D / H;
     TRY(layernorm(x, L->an_w, L->an_b, w.n, B, D, T, 0, s));
     if (L->merged) {
@@ -1621,17 +1732,18 @@ static int fft_block(const parrot_tte* t, const FftLayer* L, TteScratch& w, floa
         TRY(conv_launch(L->wo.get(), w.o, x, w.h, B, T, EPI_STORE, 1.f, 0, 0, 0, s));          // h = x + attn
     }
     TRY(layernorm(w.h, L->cn_w, L->cn_b, w.n, B, D, T, 0, s));
-    TRY(conv_launch(L->conv1.get(), w.n, nullptr, w.f, B, T, EPI_STORE, 1.f, 0, 0, 0, s));  // relu fused
-    TRY(conv_launch(L->conv2.get(), w.f, w.h, x, B, T, EPI_STORE, 1.f, 0, 0, 0, s));        // out = h + ffn
+    // (a 1x1 conv has no neighbours to leak from: only the k > 1 convs take the per-row ends)
+    TRY(conv_launch(L->conv1.get(), w.n, nullptr, w.f, B, T, EPI_STORE, 1.f, 0, 0, 0, s, t->cfg.ffn_k1 > 1 ? row_len : nullptr));  // relu fused
+    TRY(conv_launch(L->conv2.get(), w.f, w.h, x, B, T, EPI_STORE, 1.f, 0, 0, 0, s, t->cfg.ffn_k2 > 1 ? row_len : nullptr));      // out = h + ffn
     return PARROT_OK;
 }
 
 // Encode rows [row0, row0 + B) of a batch of Bfull rows: every pointer argument is the GROUP's first row; the group's encoder
 // output / duration prefix sums land in rows row0.. of `state` (sized for Bfull rows).  The encoder works row by row and pe[S] is
 // indexed by the padded length S alone (fft.py:18), so a row's result does not depend on the grouping.
-static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, int32_t Bfull, int32_t S,
-                           int32_t row0, int32_t B, float* log_dur, int64_t* dur, int32_t* out_lens, void* state, size_t state_bytes, void* ws,
-                           size_t ws_bytes, void* stream) {
+static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, const int32_t* src_len,
+                           int32_t Bfull, int32_t S, int32_t row0, int32_t B, float* log_dur, int64_t* dur, int32_t* out_lens, void* state,
+                           size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
     if (!t || !phones || !src_mask || !log_dur || !dur || !out_lens || !state || !ws) return fail(PARROT_E_INVALID, "tte_encode: null argument");
     if (Bfull <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_encode: empty batch");
     if (row0 < 0 || B <= 0 || row0 + B > Bfull) return fail(PARROT_E_INVALID, "tte_encode: row group outside the batch");
@@ -1648,7 +1760,8 @@ static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t
     st.cum += (size_t)row0 * S;
     st.out_len += row0;
     const int D = c.d_model;
-    hipLaunchKernelGGL(tte_embed_kernel, dim3((S + 63) / 64, (D + 63) / 64, B), dim3(256), 0, s, phones, t->tok, t->pe + (size_t)S * D,
+    // pe[S] of the padded batch (quirk Q1 / Q7), or -- row-exact -- pe[src_len[b]]: what the row's own B = 1 run adds (fft.py:18)
+    hipLaunchKernelGGL(tte_embed_kernel, dim3((S + 63) / 64, (D + 63) / 64, B), dim3(256), 0, s, phones, t->tok, t->pe, src_len,
                        w.x, S, D, c.vocab, t->err);
     HIP_TRY(hipGetLastError());
     auto dbg = [&](const std::vector<float*>& v, size_t idx, const float* src, size_t n) -> int {
@@ -1657,7 +1770,7 @@ static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t
     };
     TRY(dbg(t->dbg_enc, 0, w.x, (size_t)B * D * S));
     for (size_t n = 0; n < t->enc.size(); ++n) {
-        TRY(fft_block(t, t->enc[n].get(), w, w.x, src_mask, B, S, s));
+        TRY(fft_block(t, t->enc[n].get(), w, w.x, src_mask, B, S, s, src_len));
         TRY(dbg(t->dbg_enc, 1 + n, w.x, (size_t)B * D * S));
     }
     if (t->spk) {
@@ -1670,9 +1783,9 @@ static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t
     HIP_TRY(hipMemcpyAsync(st.enc_out, w.x, (size_t)B * D * S * sizeof(float), hipMemcpyDeviceToDevice, s));
     // duration predictor (duration.py:29-48): conv -> relu -> LN -> conv(pad 1) -> relu -> LN -> linear
     const int NF = c.dp_filter;
-    TRY(conv_launch(t->dp0.get(), w.x, nullptr, w.f, B, S, EPI_STORE, 1.f, 0, 0, 0, s));
+    TRY(conv_launch(t->dp0.get(), w.x, nullptr, w.f, B, S, EPI_STORE, 1.f, 0, 0, 0, s, src_len));
     TRY(layernorm(w.f, t->ln0_w, t->ln0_b, w.n, B, NF, S, 1, s));
-    TRY(conv_launch(t->dp1.get(), w.n, nullptr, w.f, B, S, EPI_STORE, 1.f, 0, 0, 0, s));
+    TRY(conv_launch(t->dp1.get(), w.n, nullptr, w.f, B, S, EPI_STORE, 1.f, 0, 0, 0, s, src_len));
     TRY(layernorm(w.f, t->ln1_w, t->ln1_b, w.n, B, NF, S, 1, s));
     TRY(conv_launch(t->dp_proj.get(), w.n, nullptr, w.o, B, S, EPI_STORE, 1.f, 0, 0, 0, s));  // (B,1,S)
     hipLaunchKernelGGL(duration_kernel, dim3(B), dim3(256), 0, s, w.o, src_mask, log_dur, dur, st.cum, st.out_len, S);
@@ -1680,15 +1793,10 @@ static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t
     HIP_TRY(hipMemcpyAsync(out_lens, st.out_len, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return PARROT_OK;
 }
-extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, int32_t B,
-                                 int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens, void* state, size_t state_bytes, void* ws,
-                                 size_t ws_bytes, void* stream) {
-    return tte_encode_rows(t, phones, src_mask, speaker, B, S, 0, B, log_dur, dur, out_lens, state, state_bytes, ws, ws_bytes, stream);
-}
-extern "C" int parrot_tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker, int32_t B,
-                                      int32_t S, int32_t row0, int32_t n_rows, float* log_dur, int64_t* dur, int32_t* out_lens, void* state,
-                                      size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
-    return tte_encode_rows(t, phones, src_mask, speaker, B, S, row0, n_rows, log_dur, dur, out_lens, state, state_bytes, ws, ws_bytes, stream);
+extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker,
+                                 const int32_t* src_len, int32_t B, int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens, void* state,
+                                 size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+    return tte_encode_rows(t, phones, src_mask, speaker, src_len, B, S, 0, B, log_dur, dur, out_lens, state, state_bytes, ws, ws_bytes, stream);
 }
 
 // Decode rows [row0, row0 + n) of the batch that parrot_tte_encode left in `state` (B rows).  ids / tgt_mask / logits point at the
@@ -1696,7 +1804,7 @@ extern "C" int parrot_tte_encode_rows(parrot_tte_t* t, const int64_t* phones, co
 // kernel of the decoder works row by row, so a row decoded in a group equals the same row decoded with the whole batch bit for bit.
 static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L, int32_t row0, int32_t B, int64_t* ids, uint8_t* tgt_mask,
                            float* logits, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream, int lane, bool guard_restart,
-                           bool new_batch) {
+                           bool new_batch, bool row_exact) {
     if (lane < 0 || lane >= parrot_tte::LANES) return fail(PARROT_E_INVALID, "tte_decode: lane out of range");
     if (!t || !ids || !tgt_mask || !state || !ws) return fail(PARROT_E_INVALID, "tte_decode: null argument");
     if (Bfull <= 0 || S <= 0) return fail(PARROT_E_INVALID, "tte_decode: empty batch");
@@ -1717,7 +1825,7 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
     float* const gref = t->gref ? t->gref + (size_t)lane * TIE_GUARD_MAX * V : nullptr;
     t->lanes_used = (new_batch ? 0 : t->lanes_used) | (1 << lane);
     hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, st.enc_out + (size_t)row0 * D * S, st.cum + (size_t)row0 * S,
-                       st.out_len + row0, t->pe + (size_t)L * D, w.x, tgt_mask, S, L, D, t->guard > 0.f ? gstat : nullptr, guard_restart ? 1 : 0);
+                       st.out_len + row0, t->pe, w.x, tgt_mask, S, L, D, t->guard > 0.f ? gstat : nullptr, guard_restart ? 1 : 0, row_exact ? 1 : 0);
     HIP_TRY(hipGetLastError());
     auto dbg = [&](size_t idx, const float* src, size_t n) -> int {
         if (idx < t->dbg_dec.size() && t->dbg_dec[idx])
@@ -1726,7 +1834,7 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
     };
     TRY(dbg(0, w.x, (size_t)B * D * L));
     for (size_t n = 0; n < t->dec.size(); ++n) {
-        TRY(fft_block(t, t->dec[n].get(), w, w.x, tgt_mask, B, L, s));
+        TRY(fft_block(t, t->dec[n].get(), w, w.x, tgt_mask, B, L, s, row_exact ? st.out_len + row0 : nullptr));
         TRY(dbg(1 + n, w.x, (size_t)B * D * L));
     }
     TRY(conv_launch(t->head.get(), w.x, nullptr, w.logits, B, L, EPI_STORE, 1.f, 0, 0, 0, s));
@@ -1752,15 +1860,9 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
     }
     return PARROT_OK;
 }
-extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int64_t* ids, uint8_t* tgt_mask, float* logits,
-                                 void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
-    return tte_decode_rows(t, B, S, L, 0, B, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream, 0, true, true);
-}
-extern "C" int parrot_tte_decode_rows(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int32_t row0, int32_t n_rows, int32_t lane,
-                                      int32_t flags, int64_t* ids, uint8_t* tgt_mask, float* logits, void* state, size_t state_bytes,
-                                      void* ws, size_t ws_bytes, void* stream) {
-    return tte_decode_rows(t, B, S, L, row0, n_rows, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream, lane,
-                           (flags & PARROT_ROWS_GUARD_RESTART) != 0, (flags & PARROT_ROWS_NEW_BATCH) != 0);
+extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int32_t row_exact, int64_t* ids, uint8_t* tgt_mask,
+                                 float* logits, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+    return tte_decode_rows(t, B, S, L, 0, B, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream, 0, true, true, row_exact != 0);
 }
 
 extern "C" int parrot_tte_debug_stages(parrot_tte_t* t, float* const* enc_ptrs, float* const* dec_ptrs) {
@@ -1799,7 +1901,7 @@ extern "C" int parrot_length_regulator(const float* seq, const int64_t* dur, int
     // (B,S,D) -> (B,D,S): the transpose kernel with the roles of C and T swapped
     hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((D + 63) / 64, (S + 63) / 64, B), dim3(256), 0, s, seq, seq_cf, S, D);
     hipLaunchKernelGGL(dur_prefix_kernel, dim3(B), dim3(256), 0, s, dur, cum, lens, S);
-    hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, seq_cf, cum, lens, zero, out_cf, mask, S, L, D);
+    hipLaunchKernelGGL(length_regulate_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, seq_cf, cum, lens, zero, out_cf, mask, S, L, D, nullptr, 1, 0, 0);
     hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((L + 63) / 64, (D + 63) / 64, B), dim3(256), 0, s, out_cf, out, D, L);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_lens, lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));

@@ -30,17 +30,32 @@
 
 namespace parrot {
 
-constexpr int RBS_MAX_CONVS = 8;
+constexpr int RBS_MAX_CONVS = 8;    // convs of one ResBlock (pairs x 2)
+constexpr int RBS_MAX_BRANCH = 4;   // MRF branches of a stage (PARROT_MAX_KERNELS)
+constexpr int RBS_MAX_ALL = RBS_MAX_CONVS * RBS_MAX_BRANCH;
+
+// experiment switches (tools/build_exp.sh): wave priority of the MFMA phase / of the conversion phase (0 = leave it alone)
+#ifndef RBS_PRIO_CONV
+#define RBS_PRIO_CONV 0
+#endif
+#ifndef RBS_PRIO_WP
+#define RBS_PRIO_WP 0
+#endif
 
 struct ResblockSplitParams {
     const float* x;           // (B, C, T) input of the first pair of this launch (C = 32 or 16: the kernel's)
     float* y;                 // (B, C, T) output (MRF accumulator or an intermediate buffer)
     const uint16_t* wstream;  // this launch's first step in the ResBlock's concatenated weight stream (padded past the end for the prefetch)
-    const float* bias[RBS_MAX_CONVS];
-    float wsc[RBS_MAX_CONVS];  // per-conv weight scale of the stream (power of two; 1 for the bf16 schemes)
-    int dil[RBS_MAX_CONVS];
-    int n_conv;               // convs in this launch (even: whole pairs)
+    const float* bias[RBS_MAX_ALL];
+    float wsc[RBS_MAX_ALL];  // per-conv weight scale of the stream (power of two; 1 for the bf16 schemes)
+    int dil[RBS_MAX_ALL];
+    int n_conv;               // convs in this launch (even: whole pairs); whole-MRF launches: convs per branch
     int k;                    // taps of every conv of the block
+    // whole-MRF launches (the MRF instantiations): every ResBlock branch of the stage in ONE launch -- conv m of branch j is entry
+    // j * n_conv + m of the arrays above, branch j walks its own weight stream with its own tap count; y = sum_j branch_j(x) / div
+    int n_branch;
+    const uint16_t* bstream[RBS_MAX_BRANCH];
+    int bk[RBS_MAX_BRANCH];
     int T, B;
     int H;                    // total reach of this launch's convs
     int TT;                   // output columns per workgroup = W - 2H
@@ -59,11 +74,19 @@ constexpr int RBS_W = 384;  // 32-channel window (the 64-channel kernel uses hal
 //                              4 -> 64 channels, 2 (row tiles) x 2 (column halves) waves (window 192);
 //                              8 -> 128 channels, 4 row tiles, one column group (window 96);
 //                             16 -> 256 channels, 8 waves = 8 row tiles, one column group (window 96, 96 KiB of LDS: one workgroup per CU).
-template <class SCH, int NCH>
-__global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 3 ? 2 : 3)) void resblock_split_kernel(const ResblockSplitParams p) {
+// WN = column groups (waves side by side; 0 = the pair kernels' own: 4 waves per workgroup up to 128 channels).  MRF = whole-stage
+// launches: all ResBlock branches of an MRF stage per window, the branch sum in registers (x is read once per branch -- from L2
+// after the first -- and y written ONCE per stage instead of three launches that each re-read x and read-modify-write the sum).
+// The MRF instantiations run 8 waves on a twice-as-wide window (32 channels: 768 columns, 64 channels: 384; 96 KiB of LDS, one
+// workgroup per CU, <= 256 VGPRs): 18 convs per window amortise the window's load / store, which a single resident workgroup
+// cannot hide behind another's MFMAs, and the total reach of the k = 11 branch (60 columns) still leaves 84 % / 69 % of a window.
+constexpr int rbs_default_wn(int nch) { return (nch / 2 >= 4) ? 1 : 4 / (nch / 2); }
+template <class SCH, int NCH, int WN = 0, bool MRF = false>
+__global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
+                             ((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64 == 512) ? 1 : (SCH::NP == 3 ? 2 : 3)) void resblock_split_kernel(const ResblockSplitParams p) {
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
-    constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = (WAVES_M >= 4) ? 1 : 4 / WAVES_M, NTW = 3, W = WAVES_N * NTW * 32;
-    const int K = p.k;
+    constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = WN ? WN : rbs_default_wn(NCH), NTW = 3, W = WAVES_N * NTW * 32;
+    int K = MRF ? p.bk[0] : p.k;
     // operand buffer: [piece][chunk][octet][col][8 channels]: 16 bytes per (column, octet), columns contiguous -- both the
     // 16-byte stores of write_p and the ds_read_b128 fragment reads at any tap shift walk consecutive addresses across lanes
     constexpr int OCT_BYTES = W * 16, CH_BYTES = 2 * OCT_BYTES, PIECE_BYTES = NCH * CH_BYTES;
@@ -94,7 +117,7 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
 
     // ---- R <- x window, in the C/D layout: row m = 32 wm + (r & 3) + 8 (r >> 2) + 4 half, column = lane & 31 -----
     f32x16 R[NTW], acc[NTW];
-    {
+    auto load_r = [&]() __attribute__((always_inline)) {
         const size_t xaddr = reinterpret_cast<size_t>(p.x + (size_t)b * C * p.T);
         const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
         const __amdgpu_buffer_rsrc_t xrsrc =
@@ -107,12 +130,14 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
             for (int r = 0; r < 16; ++r)
                 R[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, (32 * wm + (r & 3) + 8 * (r >> 2)) * row_bytes, 0));
         }
-    }
+    };
+    load_r();
 
     // ---- accumulator tile -> operand buffer: (leaky ReLU,) sequence mask, 3-way split, two 8-byte stores per
     //      (tile, chunk, piece, row group): rows 8q+4g+{0..3} of this half are channels 16 (2 wm + q) + 8g + 4 half + {0..3}
     // `mul`: (power-of-two) factor taking v to the operand scale XS (v may be a scaled accumulator)
     auto write_p = [&](const f32x16 (&v)[NTW], float mul) __attribute__((always_inline)) {
+        if constexpr (RBS_PRIO_WP != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_WP);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const float m2 = (SCH::XS != 1.f) ? mul * p.slope : p.slope;
@@ -153,21 +178,24 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
                             *reinterpret_cast<uint4*>(smem_raw + (2 * wm + q) * CH_BYTES + half * OCT_BYTES + col[nt] * 16 + pc * PIECE_BYTES) = uint4{0u, 0u, 0u, 0u};
                 }
         }
+        if constexpr (RBS_PRIO_WP != 0) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- weights: one buffer descriptor, per-lane constant offset, scalar step offset ----------------------------
     // stream order: [conv][row tile][chunk * K + tap]; this wave walks its own row tile's steps
-    const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(p.wstream));
-    const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<size_t>(p.wstream) >> 32));
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)w_hi << 32) | w_lo), 0, 0x7fffffff, 0x00020000);
+    auto stream_rsrc = [&](const uint16_t* ws) __attribute__((always_inline)) {
+        const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(ws));
+        const unsigned w_hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<size_t>(ws) >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)w_hi << 32) | w_lo), 0, 0x7fffffff, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t wrsrc = stream_rsrc(MRF ? p.bstream[0] : p.wstream);
     const unsigned lane16 = lane * 16;
     s16x8 A[2][NPC], Bv[2][NTW][NPC];
     auto load_a_piece = [&](s16x8 (&a)[NPC], int pc, int gstep) __attribute__((always_inline)) {
         a[pc] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + pc * 1024, gstep * STEP_BYTES, 0));
     };
-    const int conv_steps = WAVES_M * NCH * K;  // steps of one conv in the stream
-    int gbase = wm * NCH * K;                  // this wave's first step of the current conv
+    int conv_steps = WAVES_M * NCH * K;  // steps of one conv in the stream
+    int gbase = wm * NCH * K;            // this wave's first step of the current conv
 #pragma unroll
     for (int pc = 0; pc < NPC; ++pc) {
         load_a_piece(A[0], pc, gbase);      // (tap 0, chunk 0)
@@ -177,7 +205,7 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
     write_p(R, SCH::XS);  // (out-of-sequence columns of R are 0 from the range-checked loads)
     __syncthreads();
 
-    const int center = (K - 1) / 2;
+    int center = (K - 1) / 2;
     auto load_b = [&](s16x8 (&bb)[NTW][NPC], int ch, int shift) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -193,6 +221,7 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
     // conv's tap 0) right after its last use, and the operand fragments of the next step are read during the current one.
     // (A last, discarded fragment read follows the final step; the stream is padded by one conv for the prefetch.)
     auto conv = [&](int dil) __attribute__((always_inline)) {
+        if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_CONV);
         load_b(Bv[0], 0, -center * dil);
         for (int j = 0; j < K; ++j) {
             const int shift = (j - center) * dil;
@@ -233,13 +262,34 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
             __builtin_amdgcn_sched_barrier(0);
         }
         gbase += conv_steps;
+        if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(0);
     };
     auto bias_rows = [&](const float* __restrict__ bias, float (&bv)[16]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[r] = bias[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half];
     };
 
-    for (int m = 0; m < p.n_conv; m += 2) {
+    f32x16 XSr[MRF ? NTW : 1];  // whole-MRF launches: the branch sum (models.py:100-106), in branch order
+    const int n_branch = MRF ? p.n_branch : 1;
+    for (int br = 0; br < n_branch; ++br) {
+    if (MRF && br > 0) {  // next branch: its own tap count and weight stream, R <- the stage input again (an L2 hit by now)
+        K = p.bk[br];
+        center = (K - 1) / 2;
+        conv_steps = WAVES_M * NCH * K;
+        gbase = wm * NCH * K;
+        wrsrc = stream_rsrc(p.bstream[br]);
+        load_r();
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) {
+            load_a_piece(A[0], pc, gbase);
+            load_a_piece(A[1], pc, gbase + K);
+        }
+        __syncthreads();  // every wave is done with the previous branch's last conv (reads of P)
+        write_p(R, SCH::XS);
+        __syncthreads();
+    }
+    for (int mm = 0; mm < p.n_conv; mm += 2) {
+        const int m = br * p.n_conv + mm;  // (pair kernels: one branch, m = mm)
         float bv[16];
         // h = conv_d(P) + b1   (accumulator scale s1 = XS * wsc[m])
         const float s1 = SCH::XS * p.wsc[m], s2 = SCH::XS * p.wsc[m + 1];
@@ -268,12 +318,19 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
             for (int r = 0; r < 16; ++r) R[nt][r] = (SCH::XS != 1.f) ? acc[nt][r] * i2 : acc[nt][r];
         // (columns outside the sequence now hold garbage in R: they never feed a valid column -- write_p zeroes their operand slots --
         //  and the final store drops them or leaves them in the row's unspecified tail)
-        if (m + 2 < p.n_conv) {
+        if (mm + 2 < p.n_conv) {
             __syncthreads();
             write_p(R, SCH::XS);
             __syncthreads();
         }
     }
+    if constexpr (MRF) {  // xs = rb_0(x), then xs += rb_j(x): the same adds, in the same order, as the per-branch launches' epilogues
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) XSr[nt][r] = (br == 0) ? 0.f + R[nt][r] : XSr[nt][r] + R[nt][r];
+    }
+    }  // branches
 
     // ---- write the central TT columns (registers -> global, 128-byte runs per row) ---------------------------------
     // buffer-addressed like the layer kernels' RowTile (conv_mfma.h): ONE lane-dependent offset per column tile (0x80000000 for a
@@ -281,7 +338,7 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
     // arithmetic and per-element selects of the first version were ~600 VALU instructions per window, two conversion passes' worth
     const RowTile yt = row_tile(p.y + (size_t)b * C * p.T, C, p.T);
     const int row_bytes = p.T * 4;
-    const bool has_acc = p.epi != EPI_STORE;
+    const bool has_acc = !MRF && p.epi != EPI_STORE;
     const bool do_div = p.epi == EPI_ADD_DIV;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
@@ -290,7 +347,10 @@ __global__ __launch_bounds__(NCH == 16 ? 512 : 256, NCH == 16 ? 1 : (SCH::NP == 
         const bool ok = c >= 0 && c < p.TT && t < p.T;
         const int voff = ok ? (4 * half * p.T + t) * 4 : (int)0x80000000;
         float v[16];
-        if (has_acc) {
+        if constexpr (MRF) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = (n_branch > 1) ? XSr[nt][r] / p.div : XSr[nt][r];
+        } else if (has_acc) {
             float yv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) yv[r] = row_tile_load(yt, voff, (32 * wm + (r & 3) + 8 * (r >> 2)) * row_bytes);
@@ -362,6 +422,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
         }
     }
     auto write_p = [&](const f32x4 (&v)[NT], float mul) __attribute__((always_inline)) {
+        if constexpr (RBS_PRIO_WP != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_WP);
         const float m2 = (SCH::XS != 1.f) ? mul * p.slope : p.slope;
 #pragma unroll
         for (int np = 0; np < NT; np += 2) {  // tile pairs: lane groups with even g4 end up owning tile np's octet, odd ones tile np+1's
@@ -398,6 +459,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
                 }
             }
         }
+        if constexpr (RBS_PRIO_WP != 0) __builtin_amdgcn_s_setprio(0);
     };
 
     const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(p.wstream));
@@ -438,6 +500,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
         // finite -- 0 x inf = NaN -- and, with unclamped reads, columns beyond the conv's true reach may hold anything: those lanes
         // re-read tap K - 1 (inside the reach, finite wherever the output column is valid) instead of stepping one tap further out.
         const int tpd_last = tpd - (((K & 1) && (g4 >> 1)) ? dil : 0);
+        if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_CONV);
         load_b(Bv[0], 0, S == 1 ? tpd_last : tpd);
         for (int s2 = 0; s2 < S; s2 += 2) {
 #pragma unroll
@@ -478,6 +541,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
             __builtin_amdgcn_sched_barrier(0);
         }
         gstep += S;
+        if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(0);
     };
 
     for (int m = 0; m < p.n_conv; m += 2) {
@@ -564,6 +628,34 @@ inline hipError_t launch_resblock_split_s(int C, const ResblockSplitParams& p, h
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(C == 256 ? 512 : 256), lds, s, p);
     return hipGetLastError();
 }
+// whole-MRF launches (32 / 64 channels): 8 waves, 768- / 384-column window, NP x 48 KiB of LDS
+constexpr int rbs_mrf_window(int C) { return C == 32 ? 768 : C == 64 ? 384 : 0; }
+inline bool resblock_mrf_has(int C) { return C == 32 || C == 64; }
+template <class SCH>
+inline hipError_t launch_mrf_split_s(int C, const ResblockSplitParams& p, hipStream_t s) {
+    if (!resblock_mrf_has(C)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)SCH::NP * 49152;
+    auto kern = (C == 32) ? resblock_split_kernel<SCH, 2, 8, true> : resblock_split_kernel<SCH, 4, 4, true>;
+    static DynLdsOnce lds_once[2];
+    {
+        hipError_t e = ensure_dyn_lds(lds_once[C == 32 ? 0 : 1], reinterpret_cast<const void*>(kern), lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_mrf_split_f16x3(int C, const ResblockSplitParams& p, hipStream_t s);   // csrc/tu_mrf.hip
+hipError_t launch_mrf_split_bf16(int C, const ResblockSplitParams& p, hipStream_t s);    // csrc/tu_mrf_single.hip
+hipError_t launch_mrf_split_f16(int C, const ResblockSplitParams& p, hipStream_t s);     // csrc/tu_mrf_single.hip
+inline hipError_t launch_mrf_split(int scheme, int C, const ResblockSplitParams& p, hipStream_t s) {
+    switch (scheme) {
+        case SchF16x3::ID: return launch_mrf_split_f16x3(C, p, s);
+        case SchBf16::ID: return launch_mrf_split_bf16(C, p, s);
+        case SchF16::ID: return launch_mrf_split_f16(C, p, s);
+        default: return hipErrorInvalidValue;  // (three bf16 pieces: R + accumulators + branch sum + fragments do not fit 256 VGPRs)
+    }
+}
+inline bool resblock_mrf_scheme(int scheme) { return scheme == SchF16x3::ID || scheme == SchBf16::ID || scheme == SchF16::ID; }
 hipError_t launch_resblock_split_f16x3(int C, const ResblockSplitParams& p, hipStream_t s);   // csrc/tu_resblock.hip
 hipError_t launch_resblock_split_bf16x6(int C, const ResblockSplitParams& p, hipStream_t s);  // csrc/tu_resblock.hip
 hipError_t launch_resblock_split_bf16(int C, const ResblockSplitParams& p, hipStream_t s);    // csrc/tu_split_single.hip

@@ -125,6 +125,7 @@ def gather_waveforms(wav: torch.Tensor, dst: int = 0, equal_shapes: bool = False
 
 
 _gather_mode = os.environ.get("PARROT_GATHER", "auto")  # auto | gather | allgather
+GATHER_FATAL_EXIT_CODE = 70  # exit status of a rank whose latched gather failed (see _collect)
 _allgather_buf: Dict[tuple, torch.Tensor] = {}
 
 
@@ -135,16 +136,27 @@ def _collect(send: torch.Tensor, out, dst: int, key) -> None:
     `all_gather_into_tensor` on a single contiguous tensor (every rank then holds a copy: world x 21 MB at B = 64)."""
     global _gather_mode
     world, rank = dist.get_world_size(), dist.get_rank()
-    if _gather_mode in ("auto", "gather"):
+    if _gather_mode == "gather":
+        # Latched (or forced) mode: no per-step agreement any more, so an error on ONE rank (a new shape, OOM, a backend hiccup)
+        # would leave its peers blocked inside the collective until the backend's watchdog fires.  It is fatal for the whole
+        # group by design: the failing rank reports and exits (PARROT_GATHER_FATAL=raise re-raises instead, for callers that
+        # tear the group down themselves) -- under torchrun / mp.spawn the launcher then ends the peers at once.
+        try:
+            dist.gather(send, out, dst=dst)
+        except RuntimeError as e:
+            if os.environ.get("PARROT_GATHER_FATAL", "exit") == "raise":
+                raise
+            import sys
+            print(f"parrot_tts_amd.dist: rank {rank}: dist.gather failed after the gather mode was latched ({e}); the peers are "
+                  "inside the collective -- ending this process so that the launcher tears the group down", file=sys.stderr, flush=True)
+            os._exit(GATHER_FATAL_EXIT_CODE)
+        return
+    if _gather_mode == "auto":
         ok = 1
         try:
             dist.gather(send, out, dst=dst)
         except RuntimeError:
-            if _gather_mode == "gather":
-                raise
             ok = 0
-        if _gather_mode == "gather":
-            return
         # all ranks must agree on the fallback (a failure on the root only would otherwise deadlock the next call).  The
         # agreement is reached ONCE: after the first call every rank latches the mode, so later steps carry no host-side
         # all_reduce (a cross-rank host barrier per step would stop the host from running ahead of the device)

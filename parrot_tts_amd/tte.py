@@ -19,8 +19,6 @@ from . import _lib
 from .ops import PREC_BF16X6, PREC_F16X3, PREC_STR, dptr, param_fingerprint, range_fallback_default, require_cuda, stream_ptr
 from .synth import sinusoid_table
 
-ROWS_GUARD_RESTART, ROWS_NEW_BATCH = 1, 2  # include/parrot_hip.h PARROT_ROWS_*
-_TTE_LANES = int(os.environ.get("PARROT_TTE_LANES", "1"))
 
 
 def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = False) -> None:
@@ -109,7 +107,6 @@ class Parrot(nn.Module):
         self._precision_override: Optional[int] = None
         self._merge_override: Optional[bool] = None  # None: library default (merged); tests build unmerged handles beside it
         self._probe_pending = False
-        self._lane_streams: list = []  # side streams of the row-group lanes (created on first use)
         # torch's load_state_dict recurses through _load_from_state_dict and never calls a CHILD's load_state_dict
         # override, so a reload through any wrapper (LitParrot, nn.Sequential ...) is caught here: the post hook runs
         # for every module of the tree, and _current_handle() also compares the parameters' version fingerprint.
@@ -209,10 +206,11 @@ class Parrot(nn.Module):
         raise IndexError(f"{who}: embedding index out of range (code {code})")
 
     @torch.no_grad()
-    def _encode(self, batch, status_hooks=()) -> dict:
+    def _encode(self, batch, status_hooks=(), row_exact: bool = False) -> dict:
         """Phase 1 (encoder, duration predictor) and the ONE device-to-host transfer of the path (the expanded lengths: the
         reference's own host sync, duration.py:10).  ``status_hooks``: callables ``hook(dst_ptr, stream_ptr) -> name`` that enqueue a
         copy of another handle's device status flag (the vocoder's, see SynthesisPipeline): they ride on that transfer.
+        ``row_exact``: every row is evaluated as the reference evaluates that utterance ALONE (see ``infer``).
         Returns the context ``_decode`` continues from."""
         phones = batch["phones"]
         require_cuda(phones, "batch['phones']")
@@ -223,6 +221,10 @@ class Parrot(nn.Module):
         B, S = phones.shape
         src_mask = batch["src_mask"].to(dev)
         valid = src_mask.to(torch.uint8).contiguous()
+        src_len = None
+        if row_exact:  # real tokens per row; the key mask is that prefix (collate pads on the right, modules/data.py:97-104)
+            src_len = valid.sum(1, dtype=torch.int32).contiguous()
+            valid = (torch.arange(S, device=dev)[None, :] < src_len[:, None]).to(torch.uint8).contiguous()
         speaker = None
         if self.n_speaker > 1:
             speaker = batch["speaker"].to(dev, torch.int64).contiguous()
@@ -235,13 +237,10 @@ class Parrot(nn.Module):
         st = stream_ptr(dev)
         with torch.cuda.device(dev):
             try:
-                def enc(row0, n):  # (on the current stream)
-                    ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, n, S, 0), dtype=torch.uint8, device=dev)
-                    _lib.check(lib.parrot_tte_encode_rows(self._handle, dptr(phones[row0:]), dptr(valid[row0:]),
-                                                          dptr(speaker[row0:]) if speaker is not None else None, B, S, row0, n,
-                                                          dptr(log_dur[row0:]), dptr(dur[row0:]), dptr(lens[row0:]), dptr(state), state.numel(),
-                                                          dptr(ws), ws.numel(), stream_ptr(dev)))
-                self._on_lanes(dev, self._lanes(B), enc, (phones, valid, speaker, log_dur, dur, status, state))
+                ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, B, S, 0), dtype=torch.uint8, device=dev)
+                _lib.check(lib.parrot_tte_encode(self._handle, dptr(phones), dptr(valid), dptr(speaker) if speaker is not None else None,
+                                                 dptr(src_len) if src_len is not None else None, B, S, dptr(log_dur), dptr(dur), dptr(lens),
+                                                 dptr(state), state.numel(), dptr(ws), ws.numel(), st))
                 _lib.check(lib.parrot_tte_status_async(self._handle, status.data_ptr() + 4 * B, st))
                 hooked = [hook(status.data_ptr() + 4 * (B + 1 + i), st) for i, hook in enumerate(status_hooks)]
                 hooked = [h if isinstance(h, tuple) else (h, None) for h in hooked]  # (name, on_nonfinite callback or None)
@@ -259,7 +258,7 @@ class Parrot(nn.Module):
                 on_nonfinite()
             self._raise_status(int(status_h[B + 1 + i]), nm)
         return {"B": B, "S": S, "L": int(lens_h.max()), "dev": dev, "state": state, "log_dur": log_dur, "dur": dur, "lens": lens_h,
-                "lens_dev": lens, "src_mask": src_mask, "handle": self._handle}
+                "lens_dev": lens, "src_mask": src_mask, "handle": self._handle, "row_exact": bool(row_exact)}
 
     @staticmethod
     def _reraise(e):
@@ -269,90 +268,32 @@ class Parrot(nn.Module):
             raise FloatingPointError(str(e)) from None
         raise e
 
-    # ---- lanes: row groups of one batch on concurrent streams ------------------------------------------------------------
-    # parrot_tte_encode_rows / _decode_rows let row groups of one batch encode / decode side by side on several streams (rows are
-    # bit-identical to the whole-batch run: tests/test_gpu_round4.py).  The idea -- one group's LayerNorm / attention / 1x1
-    # launches under the other's FFN conv -- does NOT pay at B = 64 (S = 64 -> L = 256): 18.50 ms per step with one lane, 18.70 with
-    # two, 18.85 with four (tools/step_time.py): a 32-row launch is hardly shorter than a 64-row one, the single host thread
-    # enqueues the lanes one after the other (45-60 launches each), and fork / join events add their own gaps.  PARROT_TTE_LANES
-    # (default 1 = off, at most 4) keeps it as an option; groups have at least 16 rows.
-    def _lanes(self, B: int):
-        n = max(1, min(_TTE_LANES, 4, B // 16))
-        base, rem = divmod(B, n)
-        out, b0 = [], 0
-        for i in range(n):
-            k = base + (1 if i < rem else 0)
-            out.append((b0, k))
-            b0 += k
-        return out
-
-    def _on_lanes(self, dev, lanes, fn, shared) -> None:
-        """Run ``fn(row0, n)`` for every lane: lane 0 on the current stream, the others on this module's side streams, forked
-        from / joined to the current stream with events.  ``shared``: tensors of the current stream that the lanes touch."""
-        if len(lanes) == 1:
-            fn(*lanes[0])
-            return
-        cur = torch.cuda.current_stream(dev)
-        while len(self._lane_streams) < len(lanes) - 1:
-            self._lane_streams.append(torch.cuda.Stream(device=dev))
-        fork = cur.record_event()
-        joins = []
-        for l, (row0, n) in enumerate(lanes):
-            if l == 0:
-                fn(row0, n)
-                continue
-            sl = self._lane_streams[l - 1]
-            with torch.cuda.stream(sl):
-                sl.wait_event(fork)
-                fn(row0, n)
-                joins.append(sl.record_event())
-            for t in shared:
-                if t is not None:
-                    t.record_stream(sl)
-        for e in joins:
-            cur.wait_event(e)
-
-    def _decode_lanes(self, ctx: dict, ids: torch.Tensor, tgt: torch.Tensor, logits: Optional[torch.Tensor]) -> None:
-        """Phase 2 of the whole batch, its row groups side by side on the lanes (tie-guard lane = stream lane)."""
-        lanes = self._lanes(ctx["B"])
-        lane_of = {row0: l for l, (row0, _) in enumerate(lanes)}
-        self._on_lanes(ctx["dev"], lanes,
-                       lambda row0, n: self._decode(ctx, ids, tgt, logits, row0, n, lane=lane_of[row0],
-                                                    flags=ROWS_GUARD_RESTART | (ROWS_NEW_BATCH if row0 == 0 else 0)),
-                       (ids, tgt, logits, ctx["state"]))
-
     @torch.no_grad()
-    def _decode(self, ctx: dict, ids: torch.Tensor, tgt: torch.Tensor, logits: Optional[torch.Tensor], row0: int = 0,
-                n_rows: Optional[int] = None, lane: int = 0, flags: Optional[int] = None) -> None:
-        """Phase 2 for rows [row0, row0 + n_rows) of the encoded batch, on the CURRENT stream: length regulator, decoder, head,
-        argmax (+ tie guard) into rows row0.. of ``ids`` / ``tgt`` (/ ``logits``), which hold the whole batch.  The expanded length
-        L is the whole batch's (quirk Q7: pe[L] is indexed by the batch-max length), so a row's result does not depend on how the
-        batch is cut into groups.  The scratch buffer is allocated on the current stream."""
+    def _decode(self, ctx: dict, ids: torch.Tensor, tgt: torch.Tensor, logits: Optional[torch.Tensor]) -> None:
+        """Phase 2 of the encoded batch, on the CURRENT stream: length regulator, decoder, head, argmax (+ tie guard) into
+        ``ids`` / ``tgt`` (/ ``logits``).  The scratch buffer is allocated on the current stream."""
         lib = _lib.lib()
         B, S, L, dev = ctx["B"], ctx["S"], ctx["L"], ctx["dev"]
-        n = B - row0 if n_rows is None else n_rows
-        ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, n, S, L), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.parrot_tte_workspace_bytes(self._handle, B, S, L), dtype=torch.uint8, device=dev)
         state = ctx["state"]
         state.record_stream(torch.cuda.current_stream(dev))
         with torch.cuda.device(dev):
             try:
-                if flags is None:  # groups of one lane in row order: the first restarts the guard statistics
-                    flags = (ROWS_GUARD_RESTART | ROWS_NEW_BATCH) if row0 == 0 else 0
-                _lib.check(lib.parrot_tte_decode_rows(self._handle, B, S, L, row0, n, lane, flags, dptr(ids[row0:]), dptr(tgt[row0:]),
-                                                      dptr(logits[row0:]) if logits is not None else None, dptr(state), state.numel(),
-                                                      dptr(ws), ws.numel(), stream_ptr(dev)))
+                _lib.check(lib.parrot_tte_decode(self._handle, B, S, L, 1 if ctx["row_exact"] else 0, dptr(ids), dptr(tgt),
+                                                 dptr(logits) if logits is not None else None, dptr(state), state.numel(),
+                                                 dptr(ws), ws.numel(), stream_ptr(dev)))
             except _lib.ParrotHipError as e:
                 self._reraise(e)
 
     @torch.no_grad()
-    def _run(self, batch, want_logits: bool, status_hooks=()):
-        ctx = self._encode(batch, status_hooks)
+    def _run(self, batch, want_logits: bool, status_hooks=(), row_exact: bool = False):
+        ctx = self._encode(batch, status_hooks, row_exact=row_exact)
         lib = _lib.lib()
         B, L, dev = ctx["B"], ctx["L"], ctx["dev"]
         ids = torch.empty((B, L), dtype=torch.int64, device=dev)
         tgt = torch.empty((B, L), dtype=torch.uint8, device=dev)
         logits = torch.empty((B, L, lib_n_codes(self)), dtype=torch.float32, device=dev) if want_logits else None
-        self._decode_lanes(ctx, ids, tgt, logits)
+        self._decode(ctx, ids, tgt, logits)
         if self._probe_pending:  # first decode of this handle: one synchronous look at the device flag
             self._probe_pending = False
             if self.range_fallback and int(lib.parrot_tte_precision(self._handle)) == PREC_F16X3:
@@ -363,9 +304,12 @@ class Parrot(nn.Module):
                     if int(flag.cpu()) == 5:
                         _lib.check(lib.parrot_tte_status_async(self._handle, dptr(flag), st))  # handled here: clear it
                         if self._fall_back("the first decode of this handle produced non-finite logits"):
-                            return self._run(batch, want_logits, status_hooks=())
-        return {"ids": ids, "tgt_mask": tgt.bool(), "log_dur": ctx["log_dur"], "dur": ctx["dur"], "lens": ctx["lens"], "logits": logits,
-                "src_mask": ctx["src_mask"], "lens_dev": ctx["lens_dev"]}
+                            return self._run(batch, want_logits, status_hooks=(), row_exact=row_exact)
+        tgt_mask = tgt.bool()
+        if row_exact:  # a row alone is the longest of its batch: exactly `lens` ids, no extra frame (the device mask keeps one key
+            tgt_mask = torch.arange(L, device=dev)[None, :] < ctx["lens_dev"][:, None]  # valid for rows of length 0)
+        return {"ids": ids, "tgt_mask": tgt_mask, "log_dur": ctx["log_dur"], "dur": ctx["dur"], "lens": ctx["lens"], "logits": logits,
+                "src_mask": ctx["src_mask"], "lens_dev": ctx["lens_dev"], "row_exact": bool(row_exact)}
 
     @torch.no_grad()
     def forward_stages(self, batch) -> dict:
@@ -442,18 +386,21 @@ class Parrot(nn.Module):
         r = self._run(batch, want_logits=True)
         return (r["logits"], batch["src_mask"], r["tgt_mask"], r["log_dur"])
 
-    def infer(self, batch) -> List[List[int]]:
+    def infer(self, batch, row_exact: bool = False) -> List[List[int]]:
+        """``Parrot.infer`` of the reference (modules/parrot.py:112-120).  Default: the reference's result for THIS padded batch
+        (quirk Q7: it depends on the batch composition).  ``row_exact=True``: every row as the reference evaluates that utterance
+        alone -- what its driver, which runs batch_size = 1 (inference.py:34), writes to predictions.txt -- at batched speed."""
         assert self.training == False  # noqa: E712  (reference modules/parrot.py:113)
-        r = self._run(batch, want_logits=False)
+        r = self._run(batch, want_logits=False, row_exact=row_exact)
         self.check_outputs()  # (infer() synchronises anyway to hand python lists back)
         ids, msk = r["ids"].cpu(), r["tgt_mask"].cpu()
         return [c[m].numpy().tolist() for c, m in zip(ids, msk)]
 
-    def infer_dense(self, batch, status_hooks=()) -> dict:
+    def infer_dense(self, batch, status_hooks=(), row_exact: bool = False) -> dict:
         """Batched, device-resident result (ids (B,L), tgt_mask, lens) for pipelines that feed the vocoder
         directly instead of going through Python lists."""
         assert self.training == False  # noqa: E712
-        return self._run(batch, want_logits=False, status_hooks=status_hooks)
+        return self._run(batch, want_logits=False, status_hooks=status_hooks, row_exact=row_exact)
 
 
 def lib_n_codes(m: "Parrot") -> int:

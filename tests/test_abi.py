@@ -1,5 +1,5 @@
-"""CPU: the C-ABI library builds, loads, and exports every symbol include/parrot_hip.h declares
-(no compute calls -- there is no GPU here)."""
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/parrot_hip.h (the product interface) and
+include/parrot_hip_debug.h (test / profiling / probe entry points) declare (no compute calls -- there is no GPU here)."""
 import ctypes
 import os
 import re
@@ -16,16 +16,20 @@ def lib():
     return _lib.lib()
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "parrot_hip.h")).read()
+def _declared(header="parrot_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(parrot_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
     from parrot_tts_amd import _lib
-    names = _declared()
-    assert len(names) >= 20
+    product, debug = _declared(), _declared("parrot_hip_debug.h")
+    assert len(product) >= 20
+    # the product header carries no debug / profiling / probe entry point
+    assert not [n for n in product if "debug" in n or "prof" in n or "selftest" in n]
+    assert not set(product) & set(debug)
+    names = sorted(product + debug)
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(raw, n), f"{n} declared in parrot_hip.h but not exported"
@@ -34,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_basics(lib):
-    assert lib.parrot_abi_version() == 5
+    assert lib.parrot_abi_version() == 6
     assert lib.parrot_conv_num_tile_cfgs() >= 3
     assert isinstance(lib.parrot_last_error(), bytes)
     # argument validation happens before any HIP call
@@ -81,7 +85,7 @@ int main(int argc, char** argv) {
 }
 ''')
     hdr = tmp_path / "hdr.c"
-    hdr.write_text('#include "parrot_hip.h"\nint parrot_header_only_tu;\n')
+    hdr.write_text('#include "parrot_hip.h"\n#include "parrot_hip_debug.h"\nint parrot_header_only_tu;\n')
     subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(hdr)], check=True)
     exe = tmp_path / "abi"
     subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-ldl"], check=True)

@@ -125,3 +125,40 @@ def test_single_process_is_a_no_op():
     w = torch.randn(3, 1, 8)
     assert pdist.gather_waveforms(w) is w
     assert pdist.gather_ragged_rows([[1], [2, 3]]) == [[1], [2, 3]]
+
+
+def _worker_fail_after_latch(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from parrot_tts_amd import dist as pdist
+    pdist.init_from_env("gloo")
+    wav = torch.full((2, 1, 8), float(rank))
+    g = pdist.gather_waveforms(wav, dst=0, equal_shapes=True)  # first call: all ranks agree, the mode is latched
+    assert pdist.dist_info()["gather"] == "gather"
+    if rank == 0:
+        assert g.shape == (4, 1, 8)
+        open(os.path.join(out_dir, "latched"), "w").write("ok")
+    if rank == 1:  # a later failure on ONE rank (new shape, OOM, backend hiccup ...)
+        def boom(*a, **k):
+            raise RuntimeError("injected gather failure")
+        dist.gather = boom
+    pdist.gather_waveforms(wav, dst=0, equal_shapes=True)  # rank 0 enters the collective, rank 1 fails before it
+    open(os.path.join(out_dir, f"survived{rank}"), "w").write("no")  # (never reached on rank 1; rank 0 is ended by the launcher)
+
+
+def test_gather_failure_after_the_latch_ends_the_group_fast(tmp_path):
+    """once the gather mode is latched there is no per-step agreement, so an error on one rank used to leave its peers
+    blocked in the collective.  The failing rank now reports and exits (status 70); the launcher (mp.spawn here, torchrun in
+    production) ends the peers at once instead of letting them wait for the backend's watchdog."""
+    import time
+    from parrot_tts_amd import dist as pdist
+    t0 = time.time()
+    try:
+        mp.spawn(_worker_fail_after_latch, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+        raised = None
+    except Exception as e:  # ProcessExitedException: rank 1 ended with GATHER_FATAL_EXIT_CODE
+        raised = e
+    assert raised is not None and getattr(raised, "exit_code", None) == pdist.GATHER_FATAL_EXIT_CODE, raised
+    assert (tmp_path / "latched").read_text() == "ok"
+    assert not (tmp_path / "survived1").exists()
+    assert time.time() - t0 < 120

@@ -205,6 +205,6 @@ def test_tile_and_wave_grid_switches_do_not_change_a_bit():
     ref = hashes({})
     assert len(ref.strip().splitlines()) == 3
     # (round 4 pruned the wave-grid / tile-width experiment switches; what is left that re-partitions outputs among workgroups or
-    #  streams: the small-tile rule, the MRF branch streams, the row groups / lanes of the TTE)
-    for env in ({"PARROT_SMALL_TILES": "0"}, {"PARROT_MRF_STREAMS": "3"}, {"PARROT_MRF_STREAMS": "1", "PARROT_TTE_LANES": "2"}):
+    #  streams: the small-tile rule, the MRF branch streams; round 5 removed the row groups / lanes of the TTE)
+    for env in ({"PARROT_SMALL_TILES": "0"}, {"PARROT_MRF_STREAMS": "3"}, {"PARROT_MRF_STREAMS": "1"}):
         assert hashes(env) == ref, env

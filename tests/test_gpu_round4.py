@@ -236,7 +236,7 @@ def test_merged_vs_unmerged_projections_and_the_deep_tie_guard(tmp_path, shape):
     assert row["ids_mismatch_merged"] == 0, row
 
 
-def _pipeline_with(tmp_path, B, S, ragged, seed, row_groups, tie_head=False, forced_duration=None):
+def _pipeline_with(tmp_path, B, S, ragged, seed, tie_head=False, forced_duration=None):
     cfg, h = synth.small_tte_config(), synth.small_voc_config()
     cfg["path"]["root_path"] = str(tmp_path)
     with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
@@ -259,40 +259,14 @@ def _pipeline_with(tmp_path, B, S, ragged, seed, row_groups, tie_head=False, for
     parrot = Parrot(cfg, vocab, 0)
     parrot.load_state_dict(tsd)
     batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=seed + 1, ragged=ragged)
-    pipe = SynthesisPipeline(parrot.eval().to(DEV), _gen(h, vsd), row_groups=row_groups)
+    pipe = SynthesisPipeline(parrot.eval().to(DEV), _gen(h, vsd))
     return pipe, batch, tsd, cfg
 
 
-def test_row_groups_leave_every_output_bit_unchanged(tmp_path):
-    """The in-batch software pipeline (SynthesisPipeline row groups: decoder of rows g + 1 on a side stream beside the vocoder of
-    rows g, parrot_tte_decode_rows) must be invisible in the results: ids, masks, lengths and every valid waveform sample of a
-    ragged batch equal the whole-batch run's bit for bit, for even and uneven groupings."""
-    outs = {}
-    for g in (1, 2, 3):
-        pipe, batch, _, _ = _pipeline_with(tmp_path, 50, 13, True, 5, g)
-        gb = {k: v.to(DEV) for k, v in batch.items()}
-        pipe(gb)  # first call of the handles: whole batch (range probe)
-        assert len(pipe._groups(50)) == g
-        o = pipe(gb)
-        pipe.check()
-        torch.cuda.synchronize()
-        outs[g] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in o.items()}
-    ref = outs[1]
-    hop = 320
-    for g in (2, 3):
-        o = outs[g]
-        assert torch.equal(o["ids"], ref["ids"]) and torch.equal(o["tgt_mask"], ref["tgt_mask"]) and torch.equal(o["lens"], ref["lens"])
-        assert torch.equal(o["n_samples"], ref["n_samples"])
-        for b in range(50):
-            n = int(ref["n_samples"][b])
-            assert n % hop == 0 and torch.equal(o["wav"][b, :, :n], ref["wav"][b, :, :n]), (g, b)
-
-
-def test_row_groups_keep_the_tie_guard_working(tmp_path):
-    """Every position of this checkpoint is an exact tie between codes 5 and 17 (torch.argmax: the first).  Grouped decoding appends
-    each group's low-margin positions to the batch's guard list and refines exactly its own entries: all ids are 5 (as the oracle's),
-    the statistics cover the whole batch."""
-    pipe, batch, tsd, cfg = _pipeline_with(tmp_path, 40, 3, False, 8, 2, tie_head=True, forced_duration=2)
+def test_tie_guard_covers_a_whole_batch_of_exact_ties(tmp_path):
+    """Every position of this checkpoint is an exact tie between codes 5 and 17 (torch.argmax: the first): every position lands on
+    the guard list and is refined; all ids are 5 (as the oracle's), the statistics cover the whole batch."""
+    pipe, batch, tsd, cfg = _pipeline_with(tmp_path, 40, 3, False, 8, tie_head=True, forced_duration=2)
     gb = {k: v.to(DEV) for k, v in batch.items()}
     pipe(gb)
     o = pipe(gb)
@@ -310,32 +284,3 @@ def test_row_groups_keep_the_tie_guard_working(tmp_path):
     assert lg.shape[0] == n_pos and sorted(set(int(b) for b in pos[:, 0])) == list(range(40))  # batch rows, not rows of a group
 
 
-def test_tte_lanes_leave_every_output_bit_unchanged(tmp_path, monkeypatch):
-    """parrot_tte_encode_rows / parrot_tte_decode_rows with the row groups of a batch encoding and decoding SIDE BY SIDE on two or
-    three streams (PARROT_TTE_LANES; per-lane tie-guard lists): log-durations, durations, ids, masks, logits and the guard
-    statistics equal the one-lane run's bit for bit on a ragged batch."""
-    import parrot_tts_amd.tte as tte_mod
-    outs = {}
-    for lanes in (1, 2, 3):
-        monkeypatch.setattr(tte_mod, "_TTE_LANES", lanes)
-        # (every position is a tie -> guarded; 50 rows x <= 4 positions stay below a lane's 256-entry list)
-        pipe, batch, _, _ = _pipeline_with(tmp_path, 50, 4, True, 5, 1, tie_head=True, forced_duration=1)
-        gb = {k: v.to(DEV) for k, v in batch.items()}
-        par = pipe.parrot
-        par.infer_dense(gb)  # first decode of the handle (range probe)
-        assert len(par._lanes(50)) == lanes
-        r = par._run(gb, want_logits=True)
-        par.check_outputs()
-        gs = par.guard_stats()
-        lg, pos = par.guard_logits()
-        order = sorted(range(pos.shape[0]), key=lambda i: (int(pos[i, 0]), int(pos[i, 1])))
-        outs[lanes] = {"ids": r["ids"].cpu(), "tgt": r["tgt_mask"].cpu(), "logits": r["logits"].cpu(), "log_dur": r["log_dur"].cpu(),
-                       "dur": r["dur"].cpu(), "lens": r["lens"].clone(), "n": gs["n_guarded"], "min": gs["min_margin"],
-                       "pos": pos[order], "lg": lg[order]}
-    ref = outs[1]
-    assert ref["n"] > 0
-    for lanes in (2, 3):
-        o = outs[lanes]
-        for k in ("ids", "tgt", "logits", "log_dur", "dur", "lens", "pos", "lg"):
-            assert torch.equal(o[k], ref[k]), (lanes, k)
-        assert o["n"] == ref["n"] and o["min"] == ref["min"]

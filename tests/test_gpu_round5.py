@@ -1,0 +1,175 @@
+"""GPU tests of the round-5 changes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import parrot_oracle as O  # noqa: E402
+from parrot_tts_amd import ops, synth  # noqa: E402
+from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
+
+
+def _report(**kw):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(json.dumps(kw) + "\n")
+
+
+def _gen(h, sd):
+    g = CodeGenerator(AttrDict(h))
+    g.load_state_dict(sd)
+    return g.eval().to(DEV)
+
+
+def test_hot_golden_error_by_stage(golden_dir):
+    """on the stress golden (weights x 1.2, tanh saturated) the HIP waveform is ~2x as far from exact
+    arithmetic as the reference's own fp32 run.  Localise it: every stage activation (conv_pre, ups_i, mrf_i) of the HIP path --
+    default scheme with the fused pair kernels, the same scheme layer by layer, exact fp32 MFMA layer by layer -- and of the fp32
+    oracle against an fp64 run of the oracle, relative to the stage's own magnitude.  The table goes to the parity report
+    (DESIGN.md section 4); the assertion is the waveform bound of the parity test, stated as a number."""
+    z = np.load(os.path.join(golden_dir, "voc_full_u40_hot.npz"))
+    m = json.loads(str(z["meta"]))
+    h = synth.default_voc_config()
+    sd = synth.synth_voc_state_dict(h, seed=m["seed_w"], scale=m["scale"])
+    code, spkr = torch.from_numpy(z["code"]), torch.from_numpy(z["spkr"])
+    with torch.no_grad():
+        st64, st32 = {}, {}
+        w64 = O.code_generator_forward({k: v.double() for k, v in sd.items()}, h, code, spkr, stages=st64).numpy()
+        w32 = O.code_generator_forward(sd, h, code, spkr, stages=st32).numpy()
+    names = [k for k in st64 if k != "embed"]
+    rows = {}
+    for label, prec, fused in (("hip_f16x3_fused", "f16x3", 2), ("hip_f16x3_layerwise", "f16x3", 0), ("hip_f32_layerwise", "f32", 0),
+                               ("hip_bf16x6_fused", "bf16x6", 2)):
+        ops.set_default_precision(ops.PREC_NAMES[prec])
+        ops.set_fused_resblocks(fused)
+        try:
+            g = _gen(h, sd)
+            st = {}
+            y = g(code=code.to(DEV), spkr=spkr.to(DEV), stages=st)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_default_precision(ops.PREC_NAMES["f16x3"])
+            ops.set_fused_resblocks(2)
+        rows[label] = {k: float((st[k].cpu().double() - st64[k]).abs().max() / st64[k].abs().max()) for k in names}
+        rows[label]["wav_abs"] = float(np.abs(y.cpu().numpy().astype(np.float64) - w64).max())
+    rows["reference_fp32"] = {k: float((st32[k].double() - st64[k]).abs().max() / st64[k].abs().max()) for k in names}
+    rows["reference_fp32"]["wav_abs"] = float(np.abs(w32.astype(np.float64) - w64).max())
+    rows["stage_absmax"] = {k: float(st64[k].abs().max()) for k in names}
+    _report(test="hot_golden_error_by_stage", **rows)
+    print(json.dumps(rows, indent=1))
+    assert rows["hip_f16x3_fused"]["wav_abs"] <= 5e-4
+
+
+def _parrot(cfg, vocab, n_spk, sd, tmp_path):
+    from parrot_tts_amd.tte import Parrot
+    cfg = synth.clone_config(cfg)
+    cfg["path"]["root_path"] = str(tmp_path)
+    with open(os.path.join(str(tmp_path), "speakers.json"), "w") as f:
+        json.dump({f"s{i}": i for i in range(n_spk)}, f)
+    m = Parrot(cfg, vocab, 0)
+    m.load_state_dict(sd)
+    return m.eval().to(DEV)
+
+
+def _single_row_batch(batch, b):
+    n = int(batch["src_lens"][b])
+    return {"phones": batch["phones"][b:b + 1, :n].clone(), "src_mask": batch["src_mask"][b:b + 1, :n].clone(),
+            "speaker": batch["speaker"][b:b + 1].clone()}
+
+
+@pytest.mark.parametrize("size", ["small", "full"])
+def test_row_exact_batch_equals_single_utterance_reference_runs(tmp_path, size):
+    """the reference DRIVER runs one utterance per batch (inference.py:34), and the reference's result for a row
+    depends on the batch it is padded into (quirk Q7: pe[S] / pe[L] of the padded lengths, the `<=` mask, unmasked conv padding).
+    `row_exact=True` evaluates every row of a ragged batch as that utterance alone: ids equal 32 separate B = 1 oracle runs id for
+    id (and the HIP path's own B = 1 runs bit for bit); the default mode still equals the oracle run of the padded batch."""
+    if size == "small":
+        cfg, vocab, n_spk, B, S = synth.small_tte_config(), 40, 3, 32, 21
+    else:
+        cfg, vocab, n_spk, B, S = synth.default_tte_config(), 120, 10, 32, 40
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=77)
+    model = _parrot(cfg, vocab, n_spk, tsd, tmp_path)
+    batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=5, ragged=True)
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    got = model.infer(gb, row_exact=True)
+    r = model.infer_dense(gb, row_exact=True)
+    torch.cuda.synchronize()
+    log_dur = r["log_dur"].cpu()
+    n_checked = n_skipped = 0
+    worst = 0.0
+    for b in range(B):
+        one = _single_row_batch(batch, b)
+        with torch.no_grad():
+            ref = O.tte_forward(tsd, cfg, one)
+            ref_ids = O.tte_infer(tsd, cfg, one)[0]
+        n = int(batch["src_lens"][b])
+        worst = max(worst, float((log_dur[b, :n] - ref["log_dur"][0]).abs().max()))
+        # HIP batched row-exact == HIP run of the row alone, bit for bit (ids), whatever the margins
+        alone = model.infer({k: v.to(DEV) for k, v in one.items()})[0]
+        assert got[b] == alone, f"row {b}: row-exact batch differs from the HIP single-utterance run"
+        frac = torch.exp(ref["log_dur"][0]) - 1.0
+        dur_safe = bool(((frac - torch.floor(frac) - 0.5).abs() > 1e-4).all())
+        top2 = torch.topk(ref["logits"], 2, dim=-1).values
+        if dur_safe and bool(((top2[..., 0] - top2[..., 1]) > 1e-4).all()):
+            assert got[b] == ref_ids, f"row {b}: ids differ from the reference's single-utterance run"
+            n_checked += 1
+        else:
+            assert len(got[b]) == len(ref_ids) or not dur_safe
+            n_skipped += 1
+    assert worst <= 2e-5
+    assert n_checked >= B // 2, (n_checked, n_skipped)
+    # the default mode is untouched: the reference's padded-batch result (which differs from the single-utterance one)
+    with torch.no_grad():
+        ref_rows = O.tte_infer(tsd, cfg, batch)
+    padded = model.infer(gb)
+    assert [len(x) for x in padded] == [len(x) for x in ref_rows]
+    assert sum(int(a != b) for a, b in zip(padded, got)) > 0, "padded-batch and row-exact results should differ on a ragged batch (Q7)"
+    _report(test="tte_row_exact", size=size, rows=B, rows_checked_id_for_id=n_checked, rows_below_margin=n_skipped, log_dur_err=worst)
+
+
+def test_tte_driver_row_exact_writes_the_single_utterance_predictions(tmp_path):
+    """`tte_infer --batch_size 64 --row_exact` writes the predictions.txt that `--batch_size 1` (= the reference driver,
+    inference.py:34) writes, byte for byte; the default padded-batch mode of the same batch size does not (quirk Q7)."""
+    import pickle
+
+    import yaml
+    from parrot_tts_amd import checkpoint, data
+    from parrot_tts_amd.cli import tte_infer
+    root = tmp_path / "tte"
+    root.mkdir()
+    speakers = {"bho_f": 0, "en_m": 1}
+    (root / "speakers.json").write_text(json.dumps(speakers))
+    symbols = ["a", " ", "b", "c", "d", "e", "f"]
+    with open(root / "symbols.pkl", "wb") as f:
+        pickle.dump(symbols, f)
+    cfg = synth.small_tte_config(str(root))
+    cfg["path"]["alignment_path"] = str(root)
+    cfg["path"]["wav_path"] = str(tmp_path / "audio")
+    rng = np.random.Generator(np.random.PCG64(3))
+    recs = []
+    for i in range(70):
+        n = int(rng.integers(3, 30))
+        chars = " ".join(str(rng.choice(["a", "sil", "b", "c", "d", "e", "f"])) for _ in range(n))
+        spk = "bho_f" if i % 3 else "en_m"
+        recs.append({"audio": f"/x/{spk}_{i:03d}.wav", "speaker": spk, "characters": chars, "hubert": "1", "duration": " ".join(["1"] * n)})
+    (root / "val.txt").write_text("".join(data.format_dict_line(r) for r in recs))
+    vocab = len(symbols) + 2
+    sd = synth.synth_tte_state_dict(cfg, vocab, 2, seed=23)
+    ck = tmp_path / "parrot.ckpt"
+    checkpoint.save_lightning_style(ck, sd, cfg, vocab, 0)
+    ycfg = tmp_path / "cfg.yaml"
+    ycfg.write_text(yaml.safe_dump(cfg))
+    out = {}
+    for tag, extra in (("single", []), ("row_exact", ["--batch_size", "64", "--row_exact"]), ("padded", ["--batch_size", "64"])):
+        tte_infer.main(["--config", str(ycfg), "--checkpoint_pth", str(ck), "--device", DEV] + extra)
+        out[tag] = (root / "predictions.txt").read_bytes()
+    assert out["row_exact"] == out["single"]
+    assert out["padded"] != out["single"]

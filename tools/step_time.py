@@ -2,7 +2,7 @@
 """Wall time per step of the full pipeline (bench.py's models and inputs) WITHOUT the per-launch HIP events of bench.py's kernel
 table: same-box A/B runs of schedules and switches.
 
-    python tools/step_time.py [--batch 64] [--steps 20] [--row-groups 1 2 4] [--prof]     -> one JSON line per setting"""
+    python tools/step_time.py [--batch 64] [--steps 20] [--prof]     -> one JSON line per setting"""
 import argparse
 import json
 import os
@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--src-len", type=int, default=64)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--row-groups", type=int, nargs="+", default=[1, 2])
     ap.add_argument("--prof", action="store_true", help="also time with bench.py's per-launch HIP events switched on")
     ap.add_argument("--precision", default="f16x3")
     a = ap.parse_args()
@@ -34,9 +33,9 @@ def main():
     cfg, h, tsd, vsd, parrot, gen = bench.build_models(dev, vocab, n_spk)
     batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(a.batch, a.src_len, vocab, n_spk, seed=0).items()}
     lib = _lib.lib()
-    for rg in a.row_groups:
+    for _ in (0,):
         for prof in ([False, True] if a.prof else [False]):
-            pipe = SynthesisPipeline(parrot, gen, row_groups=rg)
+            pipe = SynthesisPipeline(parrot, gen)
             for _ in range(a.warmup):
                 pipe(batch)
             torch.cuda.synchronize()
@@ -52,7 +51,7 @@ def main():
                 names = bench.tile_names(a.precision)
                 buf = (C.c_double * (4 * len(names)))()
                 lib.parrot_prof_end(buf, len(names))
-            print(json.dumps({"batch": a.batch, "row_groups": [n for _, n in pipe._groups(a.batch)], "per_launch_events": prof,
+            print(json.dumps({"batch": a.batch, "per_launch_events": prof,
                               "ms_per_step": round(ms, 4)}), flush=True)
 
 
