@@ -46,8 +46,7 @@ TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>"
               "conv_split16_kernel<SCH,2,2,2,4>",  # the 64-row tile
               "(unused)", "conv_split16_kernel<SCH,2,2,4,5>",
               "resblock_split_kernel<SCH,4>", "resblock_split_kernel<SCH,8>", "resblock_split_kernel<SCH,16>",
-              "resblock_split_kernel<SCH,2,8,MRF>", "resblock_split_kernel<SCH,4,4,MRF>",  # whole-MRF launches (32 / 64 channels)
-              "resblock16_split_kernel<SCH,MRF>"]
+              "resblock_split_kernel<SCH,2,8,MRF>", "resblock_split_kernel<SCH,4,4,MRF>"]  # whole-MRF launches (32 / 64 channels)
 SCHEMES = {"f16x3": ("SchF16x3", 3), "bf16x6": ("SchBf16x6", 6), "bf16": ("SchBf16", 1), "f16": ("SchF16", 1), "f32": ("-", 1)}
 MFMA16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split scheme spends 3 (f16x3) or 6 (bf16x6) MFMA FMAs per algorithmic fp32 FMA
 
@@ -56,19 +55,49 @@ def tile_names(precision):
     return [n.replace("SCH", SCHEMES[precision][0]) for n in TILE_NAMES]
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN_pmc_traffic.json):
-    rocprofv3 cannot run inside the timed region, so the separately collected, calibrated counters of the same
-    command are attached here (null when no summary covers this kernel build)."""
+def pmc_profile(kernel: str):
+    """Counters of `kernel` from the newest committed PMC summary (profiles/rNN_pmc_traffic.json, tools/make_pmc_traffic.py):
+    rocprofv3 cannot run inside the timed region, so the separately collected passes of the same command on the same BUILD are
+    attached here -- HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes, calibrated), the MFMA-busy fraction (SQ pass:
+    SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES) -- with the file and the box they were measured on (nulls when no summary
+    covers this kernel build)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    out = {"traffic": None, "mfma_busy": None, "source": None, "box": None}
     if not files:
-        return None, None
+        return out
     try:
         d = json.load(open(files[-1]))
-        return d.get(kernel, {}).get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+        e = d.get(kernel, {})
+        out.update(traffic=e.get("hbm_bytes_per_launch"), mfma_busy=e.get("mfma_busy"), source=os.path.basename(files[-1]), box=d.get("_box"))
     except (OSError, ValueError):
-        return None, None
+        pass
+    return out
+
+
+def algorithmic_macs(cfg, h, S, L):
+    """Multiply-accumulates of ONE utterance of the path (real taps only): TTE at S tokens -> L units, HiFi-GAN at L units."""
+    tr, dp = cfg["transformer"], cfg["duration_predictor"]
+    D, F = tr["d_model"], tr["conv_n_filter"]
+    k1, k2 = tr["conv_kernel_sizes"]
+
+    def fft(T, layers):  # qkv + in_proj + out_proj + wo (8 D^2), QK^T + AV (2 T D), FFN
+        return layers * T * (8 * D * D + 2 * T * D + F * D * k1 + D * F * k2)
+
+    NF, dk = dp["n_filter"], dp["kernel_size"]
+    tte = fft(S, tr["encoder"]["n_layer"]) + fft(L, tr["decoder"]["n_layer"]) + S * (NF * D * dk + NF * NF * dk + NF) \
+        + L * D * cfg["preprocess"]["hubert_codes"]
+    C = h["upsample_initial_channel"]
+    T = L
+    voc = C * h.get("model_in_dim", h["embedding_dim"] * (2 if h.get("multispkr") else 1)) * 7 * T
+    n_conv = 2 if str(h.get("resblock", "1")) == "1" else 1
+    for u, k in zip(h["upsample_rates"], h["upsample_kernel_sizes"]):
+        voc += C * (C // 2) * k * T
+        C, T = C // 2, T * u
+        for rk, dil in zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"]):
+            voc += C * C * rk * T * n_conv * len(dil[: 3 if n_conv == 2 else 2])
+    voc += C * 7 * T
+    return tte, voc
 
 
 def build_models(dev, vocab=300, n_spk=10):
@@ -274,14 +303,19 @@ def main():
         gather_ev.clear()
         if profile:
             _lib.check(lib.parrot_prof_begin_row(dom_row))
+        # (HIP events around every batch, >= 10 runs, median -- next to the contract's mean over the K steps between fences)
+        step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            step_ev[i][0].record()
             out = step()
+            step_ev[i][1].record()
             wav = out if out is not None else wav
         out = drain()
         wav = out if out is not None else wav
         fence()
         elapsed = time.perf_counter() - t0
+        run.step_ms = sorted(a_.elapsed_time(b_) for a_, b_ in step_ev)
         # a run that fell back to another precision (range-safe fallback of the shims) is not the run that was asked for
         in_use = {"tte": parrot.precision_in_use if workload == "full" else precision, "vocoder": gen.precision_in_use}
         if in_use["vocoder"] not in (None, precision) or in_use["tte"] not in (None, tte_precision or precision):
@@ -300,27 +334,38 @@ def main():
                 r.update(timed[0])
                 r["measured_in"] = "the timed region (events around this kernel's launches only)"
             rows.append(r)
-        # per row: fraction of the scheme's MFMA roof and of the 8 TB/s HBM peak (algorithmic bytes), and which resource binds the
-        # kernel as measured (counters, phase traces, instruction probes)
+        # per row: fraction of the scheme's MFMA roof and of the 8 TB/s HBM peak (both from the ALGORITHMIC work of the row's
+        # launches), and which roof binds it: the arithmetic intensity of the row against the ridge of its pipe.  `why` adds what the
+        # counters / traces / probes of DESIGN.md section 7 say about the distance to that roof.
         n_mf = SCHEMES[precision][1]
         for r in rows:
             k = r["kernel"]
             split_k = "_split" in k
-            r["frac_of_mfma_roof"] = r["tflops"] / ((MFMA16_PEAK_TFLOPS / n_mf) if split_k else FP32_MFMA_PEAK_TFLOPS)
+            roof_tf = (MFMA16_PEAK_TFLOPS / n_mf) if split_k else FP32_MFMA_PEAK_TFLOPS
+            r["frac_of_mfma_roof"] = r["tflops"] / roof_tf
             r["frac_of_hbm_peak"] = r["alg_gbs"] / HBM_PEAK_GBS
+            ai = (r["tflops"] * 1e12) / max(r["alg_gbs"] * 1e9, 1.0)      # FLOP per algorithmic byte
+            ridge = roof_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+            r["arithmetic_intensity"], r["ridge"] = ai, ridge
+            r["bound"] = "hbm" if ai < ridge else "mfma"
+            r["frac_of_binding_roof"] = r["frac_of_hbm_peak"] if ai < ridge else r["frac_of_mfma_roof"]
+            r["hbm"] = {"achieved": r["alg_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s (algorithmic)", "frac": r["frac_of_hbm_peak"]}
+            prof = pmc_profile(k)
+            r["mfma_busy"], r["traffic"], r["counters_source"] = prof["mfma_busy"], prof["traffic"], prof["source"]
             if "valu_kernel" in k:
-                r["bound"] = "hbm (fp32 FMA streaming kernel; 6.3 TB/s achievable)"
+                r["why"] = "fp32 FMA streaming kernel; 6.3 TB/s achievable"
             elif k.startswith("resblock"):
-                r["bound"] = ("operand conversion: scale / leaky ReLU / fp16 hi-lo split / LDS store of every conv input is VALU work of the same "
-                              "order as the conv's MFMAs (2.2-3.8 k clocks vs 1.2-6.3 k per lane and conv), and VALU beside MFMA costs 2-3x")
+                r["why"] = ("operand conversion (scale / leaky ReLU / fp16 hi-lo split / LDS store of every conv input) is VALU work of the order "
+                            "of the conv's MFMAs, and on gfx950 VALU does not hide under MFMA: tools/probes/interleave.hip measures "
+                            "16 + ~4 clocks per VALU per v_mfma_f32_16x16x32_f16 within a wave, +3 per VALU beside 32x32x16 (profiles/r05a_interleave.jsonl)")
             elif k.startswith("conv_split16"):
-                r["bound"] = "mfma 16-bit (power-limited clock); short-K layers (64 / 128 channels) add exposed prologue / epilogue latency"
-            elif "2,2,2,1,3" in k or "4,1,1,2,3" in k:
-                r["bound"] = "latency: 27 launches of 13-50 us (1x1 convs of the TTE, K = 256 ... 1024)"
+                r["why"] = "power-limited clock (bare MFMA stream: roofline.ceiling_probe_tflops); short-K layers add exposed prologue / epilogue"
+            elif "4,1,1,2,3" in k:
+                r["why"] = "latency: ~27 launches of 13-50 us (1x1 convs of the TTE, K = 256 ... 1024)"
             elif k.startswith("conv_split"):
-                r["bound"] = "mfma 16-bit with 27-33 % zero polyphase taps (transposed convs) + HBM (2-3 TB/s algorithmic)"
+                r["why"] = "27-33 % zero polyphase taps (transposed convs)"
             else:
-                r["bound"] = "mfma fp32"
+                r["why"] = "exact fp32 MFMA"
         rows.sort(key=lambda r: -r["ms_per_step"])
         rows.sort(key=lambda r: 0 if (timed and r["row"] == timed[0]["row"]) else 1)  # (stable: the timed-region row leads)
         n_samples = world * B * (wav.shape[-1] if wav is not None else 4 * S * 320)
@@ -395,12 +440,17 @@ def main():
 
     elapsed, rows, n_samples_step, pieces = run(a.precision, a.steps, a.warmup, overlap_steps=bool(a.overlap))
     gather_ms = run.gather_ms
+    head_step_ms = list(run.step_ms)
 
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         value = n_samples_step / (ms / 1e3)
         dom = rows[0]
-        traffic, traffic_src = pmc_traffic(dom["kernel"])
+        prof = pmc_profile(dom["kernel"])
+        traffic, traffic_src = prof["traffic"], prof["source"]
+        cfg_, h_ = pieces[0], pieces[1]
+        tte_macs, voc_macs = algorithmic_macs(cfg_, h_, S, 4 * S)
+        step_flops = 2.0 * world * B * ((tte_macs if a.workload == "full" else 0) + voc_macs)
         split = "_split" in dom["kernel"] or "resblock" in dom["kernel"]
         n_mfma = SCHEMES[a.precision][1]
         peak = MFMA16_PEAK_TFLOPS / n_mfma if split else FP32_MFMA_PEAK_TFLOPS
@@ -419,11 +469,20 @@ def main():
                                          if ceil else None),
                 "peak_note": (f"dense 16-bit MFMA peak 2500 TF / {n_mfma} MFMA(s) per algorithmic fp32 FMA ({a.precision}); the kernels are "
                               "clock/power-limited on real data (DESIGN.md section 7)" if split else "fp32 MFMA peak"),
-                "frac": dom["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": dom["avg_us"],
+                "frac": dom["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src, "traffic_box": prof["box"],
+                "mfma_busy": prof["mfma_busy"], "avg_launch_us": dom["avg_us"],
+                # the WHOLE step against the same roof: algorithmic FLOPs of the path (TTE + generator, real taps) / step time / peak
+                "step_tflops": step_flops / (ms / 1e3) / 1e12 / world, "step_frac": step_flops / (ms / 1e3) / 1e12 / world / peak,
+                "step_algorithmic_tflop": step_flops / 1e12,
                 "launches_per_step": dom["launches_per_step"], "alg_GBps": dom["alg_gbs"], "all_conv_kernels": rows}
         res = {
             "metric": "audio samples/sec (16 kHz; see config.note) + RTF, 256-unit batch-64 per GPU",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            # HIP-event time of every step of the timed region (rank 0): median / min / max next to the mean above
+            "ms_per_step_median": head_step_ms[len(head_step_ms) // 2] if head_step_ms else None,
+            "ms_per_step_min": head_step_ms[0] if head_step_ms else None, "ms_per_step_max": head_step_ms[-1] if head_step_ms else None,
+            "timing": "value / ms_per_step: wall clock over the K steps between barrier + synchronize fences (max over ranks); "
+                      "ms_per_step_median: median of the K per-step HIP-event times",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f16x3": "f32 (f16x3 split products)", "bf16x6": "f32 (bf16x6 split products)", "f32": "f32", "bf16": "bf16 products, f32 accumulate",
                       "f16": "f16 products, f32 accumulate"}[a.precision],

@@ -412,7 +412,7 @@ inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStr
     }
 }
 hipError_t launch_conv_split16_wide_f16x3(int variant, const ConvParams& p, hipStream_t s);   // csrc/tu_split16_wide.hip
-hipError_t launch_conv_split16_small_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16_small.hip
+hipError_t launch_conv_split16_small_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16.hip
 hipError_t launch_conv_split16_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16.hip
 hipError_t launch_conv_split16_bf16(int variant, const ConvParams& p, hipStream_t s);   // csrc/tu_split16_single.hip
 hipError_t launch_conv_split16_f16(int variant, const ConvParams& p, hipStream_t s);    // csrc/tu_split16_single.hip

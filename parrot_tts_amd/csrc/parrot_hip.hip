@@ -695,7 +695,28 @@ struct parrot_voc {
     hipStream_t lane_stream[MAX_LANES] = {};
     hipEvent_t ev_lane_fork = nullptr, ev_lane_join[MAX_LANES] = {};
     float* dbg_absmax = nullptr;       // parrot_voc_debug_absmax: (n_stages + 2) device floats, max |conv input| per group (caller-owned)
+    // HIP-graph replay of small forwards (PARROT_VOC_GRAPH, default on; B x U <= 8192 units): a forward is ~130 dependent launches
+    // of 7-40 us on up to three streams -- at one utterance the fork / join events and the launch gaps are a fifth of it.  A call
+    // whose every pointer and size equals an earlier call's is captured once (at its second sighting: the first warms lazy state)
+    // and replayed afterwards: the same kernels with the same arguments, the branch streams as graph edges.
+    struct Graph {
+        const void *code, *spkr, *feats, *lens, *wav, *ws;
+        int code_stride, n_feat, B, U;
+        size_t ws_bytes;
+        hipGraphExec_t exec = nullptr;
+        int seen = 0;
+        unsigned long stamp = 0;
+    };
+    static constexpr int MAX_GRAPHS = 8;
+    std::vector<Graph> graphs;
+    std::mutex graph_mu;
+    unsigned long graph_clock = 0;
+    bool graph_on = true;
+    hipStream_t cap_stream = nullptr;
     ~parrot_voc() {
+        for (Graph& g : graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (StreamSet& q : ss) {
             for (hipStream_t st : q.side)
                 if (st) (void)hipStreamDestroy(st);
@@ -890,10 +911,14 @@ static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const 
     v->mrf_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
     v->mrf_ok.assign((size_t)cfg->n_stages, 0);
     {
-        static const bool want = [] { const char* e = getenv("PARROT_MRF_FUSED"); return !e || atoi(e) != 0; }();
-        for (int i = 0; i < cfg->n_stages && want && v->fused != 0 && v->scheme >= 1 && resblock_mrf_scheme(v->scheme); ++i) {
+        // PARROT_MRF_FUSED: 1 (default) the 32-channel stage, where the launch is bit-identical to the pair kernels' and no slower
+        // (2.27 vs 2.31 ms per step at B = 64, 14 -> 2 passes over the stage's activations); 2 also the 64-channel stage (measured
+        // SLOWER: 4.92 vs 4.27 ms -- a 384-column window keeps 69 % of its columns, profiles/r05b_*); 0 off
+        static const int want = [] { const char* e = getenv("PARROT_MRF_FUSED"); return e ? atoi(e) : 1; }();
+        for (int i = 0; i < cfg->n_stages && want > 0 && v->fused != 0 && v->scheme >= 1 && resblock_mrf_scheme(v->scheme); ++i) {
             const int C = v->chan(i);
             if (cfg->resblock_type != 1 || !resblock_mrf_has(C) || per_rb > RBS_MAX_CONVS || cfg->n_kernels > RBS_MAX_BRANCH) continue;
+            if (C == 64 && want < 2) continue;
             bool ok = true;
             int Hmax = 0;
             for (int j = 0; j < cfg->n_kernels && ok; ++j) {
@@ -1087,6 +1112,18 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
     return PARROT_OK;
 }
 
+// output columns per window of a whole-MRF launch of this stage (window minus twice the widest branch's total reach)
+static int mrf_tile_cols(const parrot_voc* v, int stage) {
+    const parrot_voc_cfg& c = v->cfg;
+    const int per_rb = 2 * c.n_dil;
+    int Hmax = 0;
+    for (int j = 0; j < c.n_kernels; ++j) {
+        int H = 0;
+        for (int q = 0; q < per_rb; ++q) H += (c.resblock_kernel_sizes[j] - 1) / 2 * v->rb[(stage * c.n_kernels + j) * per_rb + q]->dil;
+        Hmax = std::max(Hmax, H);
+    }
+    return std::max(1, rbs_mrf_window(v->chan(stage)) - 2 * Hmax);
+}
 // Whole-MRF launch of a 32- / 64-channel stage (resblock_split.h, MRF instantiations): y = sum_j ResBlock_j(x) / n_kernels.
 static int mrf_split_launch(const parrot_voc* v, int stage, const float* x, float* y, int B, int T, hipStream_t s, const int32_t* row_len,
                             int row_len_mul, int row_len_add) {
@@ -1177,15 +1214,81 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
                             int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
                             float* const* stage_out, void* ws, size_t ws_bytes, void* stream, int ns_sized = 0, int lane = 0);
 
+// Small forwards through the graph cache (see parrot_voc::Graph); everything else -- and every failure of the graph path -- direct.
+static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_stride, const int64_t* spkr, const float* feats,
+                               int32_t n_feat, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out, float* const* stage_out,
+                               void* ws, size_t ws_bytes, void* stream) {
+    static const bool want = [] { const char* e = getenv("PARROT_VOC_GRAPH"); return !e || atoi(e) != 0; }();
+    hipStream_t s = (hipStream_t)stream;
+    const bool small = v && B > 0 && U > 0 && (long)B * U <= 8192;
+    if (!want || !small || !v->graph_on || stage_out || v->dbg_absmax || g_prof_on || !code || !wav_out || !ws)
+        return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+    {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone)  // the caller is capturing: stay inside ITS graph
+            return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+    }
+    std::unique_lock<std::mutex> lk(v->graph_mu);
+    parrot_voc::Graph* g = nullptr;
+    for (parrot_voc::Graph& q : v->graphs)
+        if (q.code == code && q.spkr == spkr && q.feats == feats && q.lens == unit_lens && q.wav == wav_out && q.ws == ws &&
+            q.code_stride == code_stride && q.n_feat == n_feat && q.B == B && q.U == U && q.ws_bytes == ws_bytes) {
+            g = &q;
+            break;
+        }
+    if (!g) {  // first sighting: remember it (evicting the least recently used entry), run directly
+        if ((int)v->graphs.size() >= parrot_voc::MAX_GRAPHS) {
+            size_t old = 0;
+            for (size_t i = 1; i < v->graphs.size(); ++i)
+                if (v->graphs[i].stamp < v->graphs[old].stamp) old = i;
+            if (v->graphs[old].exec) (void)hipGraphExecDestroy(v->graphs[old].exec);
+            v->graphs.erase(v->graphs.begin() + old);
+        }
+        parrot_voc::Graph q{};
+        q.code = code; q.spkr = spkr; q.feats = feats; q.lens = unit_lens; q.wav = wav_out; q.ws = ws;
+        q.code_stride = code_stride; q.n_feat = n_feat; q.B = B; q.U = U; q.ws_bytes = ws_bytes;
+        q.seen = 1;
+        q.stamp = ++v->graph_clock;
+        v->graphs.push_back(q);
+        lk.unlock();
+        return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+    }
+    g->stamp = ++v->graph_clock;
+    if (!g->exec) {  // second sighting: capture -- on the handle's own stream (the caller's may be the legacy default stream, which
+        hipGraph_t graph = nullptr;  // cannot capture); nothing runs during the capture, the instantiated graph is launched on `s` below
+        if (!v->cap_stream && hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking) != hipSuccess) v->cap_stream = nullptr;
+        if (!v->cap_stream || hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+            (void)hipGetLastError();
+            v->graph_on = false;
+            lk.unlock();
+            return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+        }
+        const int rc = voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, nullptr, ws, ws_bytes, (void*)v->cap_stream);
+        const hipError_t e_end = hipStreamEndCapture(v->cap_stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (rc != PARROT_OK || e_end != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            v->graph_on = false;  // this handle goes direct from now on (the argument errors of rc are reported by the direct run)
+            lk.unlock();
+            return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+        }
+        (void)hipGraphDestroy(graph);
+        g->exec = exec;
+    }
+    HIP_TRY(hipGraphLaunch(g->exec, s));
+    return PARROT_OK;
+}
+
 extern "C" int parrot_voc_forward(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
                                   int32_t U, float* wav_out, float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
-    return voc_forward_impl(v, code, U, spkr, nullptr, 0, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+    return voc_forward_graphed(v, code, U, spkr, nullptr, 0, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
 }
 
 extern "C" int parrot_voc_forward_feats(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const float* feats,
                                         int32_t n_feat_channels, const int32_t* unit_lens, int32_t B, int32_t U, float* wav_out,
                                         float* const* stage_out, void* ws, size_t ws_bytes, void* stream) {
-    return voc_forward_impl(v, code, U, spkr, feats, n_feat_channels, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+    return voc_forward_graphed(v, code, U, spkr, feats, n_feat_channels, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
 }
 
 // Chunk-streamed synthesis inside the library (`chunk_units`; BASELINE configs[4]): consecutive chunks of
@@ -1212,7 +1315,12 @@ extern "C" size_t parrot_voc_chunked_workspace_bytes(const parrot_voc_t* v, int3
         a.take<int32_t>((size_t)B);
         a.off = align_up(a.off, 256) + voc_ws_bytes(v, B, span, 1);
     }
-    return align_up(a.off, 256);
+    // a call that ends up on ONE lane (a single chunk, PARROT_CHUNK_LANES=1) runs its chunks with the shape's MRF branch streams
+    Arena one(nullptr, 0);
+    one.take<float>((size_t)B * span * v->up_total);
+    one.take<int32_t>((size_t)B);
+    one.off = align_up(one.off, 256) + voc_ws_bytes(v, B, span, voc_streams(v, B, span));
+    return align_up(std::max(a.off, one.off), 256);
 }
 extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, const int64_t* spkr, const int32_t* unit_lens, int32_t B,
                                           int32_t U, int32_t chunk_units, int32_t halo_units, float* wav_out, void* ws, size_t ws_bytes,
@@ -1228,8 +1336,11 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
     hipStream_t s = (hipStream_t)stream;
     const int n_chunks = (U + chunk_units - 1) / chunk_units;
     const int n_lanes = std::min(chunk_lanes(), n_chunks);
+    // lanes run WITHOUT the MRF branch streams (whole chunks overlap better than the branches of one); a call on one lane only -- a
+    // single chunk, PARROT_CHUNK_LANES=1 -- keeps the branch streams of its shape, like parrot_voc_forward on that span
+    const int ns_chunk = n_lanes > 1 ? 1 : voc_streams(v, B, span);
     Arena a(ws, ws_bytes);
-    const size_t inner = voc_ws_bytes(v, B, span, 1);
+    const size_t inner = voc_ws_bytes(v, B, span, ns_chunk);
     float* tmp[parrot_voc::MAX_LANES] = {};
     int32_t* lens[parrot_voc::MAX_LANES] = {};
     void* inner_ws[parrot_voc::MAX_LANES] = {};
@@ -1241,9 +1352,21 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
         a.off += inner;
     }
     if (!a.ok || a.off > ws_bytes) return fail(PARROT_E_NOMEM, "voc_forward_chunked: workspace too small");
-    std::unique_lock<std::mutex> side_lock(v->side_mu);  // the lane streams and events are the handle's
+    std::unique_lock<std::mutex> side_lock(v->side_mu, std::defer_lock);  // the lane streams and events are the handle's
+    if (n_lanes > 1) side_lock.lock();                                     // (one lane: voc_forward_impl takes it for its branch streams)
+    // Whatever happens below, the caller's stream must not run past work that the lanes still have queued on ws / wav_out (the
+    // caller may free them right after an error return): the join runs on every exit once the lanes have been forked.
+    struct LaneJoin {
+        parrot_voc* v; hipStream_t s; int n; bool armed;
+        ~LaneJoin() {
+            if (!armed) return;
+            for (int l = 1; l < n; ++l)
+                if (hipEventRecord(v->ev_lane_join[l], v->lane_stream[l]) == hipSuccess) (void)hipStreamWaitEvent(s, v->ev_lane_join[l], 0);
+        }
+    } join{v, s, n_lanes, false};
     if (n_lanes > 1) {  // the other lanes see what the caller's stream has produced so far (code, spkr, unit_lens)
         HIP_TRY(hipEventRecord(v->ev_lane_fork, s));
+        join.armed = true;
         for (int l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(v->lane_stream[l], v->ev_lane_fork, 0));
     }
     int c = 0;
@@ -1256,16 +1379,13 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
             hipLaunchKernelGGL(rebase_lens_kernel, dim3((B + 255) / 256), dim3(256), 0, sl, unit_lens, lens[lane], B, lo, n);
             HIP_TRY(hipGetLastError());
         }
-        // (one branch stream per chunk: what the lane's workspace was sized for)
+        // (the branch-stream count the lane's workspace was sized for)
         TRY(voc_forward_impl(v, code + lo, U, spkr, nullptr, 0, unit_lens ? lens[lane] : nullptr, B, n, tmp[lane], nullptr, inner_ws[lane], inner,
-                             (void*)sl, 1, lane));
+                             (void*)sl, ns_chunk, lane));
         HIP_TRY(hipMemcpy2DAsync(wav_out + (size_t)start * hop, (size_t)U * hop * sizeof(float), tmp[lane] + (size_t)(start - lo) * hop,
                                  (size_t)n * hop * sizeof(float), (size_t)(stop - start) * hop * sizeof(float), B, hipMemcpyDeviceToDevice, sl));
     }
-    for (int l = 1; l < n_lanes; ++l) {  // join: the caller's stream continues when every lane has written its chunks
-        HIP_TRY(hipEventRecord(v->ev_lane_join[l], v->lane_stream[l]));
-        HIP_TRY(hipStreamWaitEvent(s, v->ev_lane_join[l], 0));
-    }
+    // (join: LaneJoin's destructor -- the caller's stream continues when every lane has written its chunks)
     return PARROT_OK;
 }
 
@@ -1343,7 +1463,10 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         add = add * c.upsample_rates[i] + ((c.upsample_kernel_sizes[i] - c.upsample_rates[i]) & 1);  // out_len(n mul + add)
         const size_t n_act = (size_t)B * v->chan(i) * T;
         TRY(snap(1 + 2 * i, X, n_act));
-        if (v->mrf_ok[i] && (double)v->chan(i) * T * 4.0 < 2147483648.0) {  // every branch of the stage in ONE launch
+        // every branch of the stage in ONE launch -- when that launch fills the chip twice over (one 512-thread workgroup per CU
+        // walks 18 convs: a few windows are faster as per-branch launches on the branch streams; same bits either way at 32 channels)
+        if (v->mrf_ok[i] && (double)v->chan(i) * T * 4.0 < 2147483648.0 &&
+            (long)B * ((T + mrf_tile_cols(v, i) - 1) / mrf_tile_cols(v, i)) >= 2L * g_num_cus) {
             TRY(amax(1 + i, X, n_act, s));
             TRY(mrf_split_launch(v, i, X, XS, B, T, s, unit_lens, mul, add));
             TRY(snap(2 + 2 * i, XS, n_act));

@@ -220,7 +220,7 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
     // in place for the step two ahead (chunk + 2 of this tap, else chunk + 2 - NCH of the next tap, else of the next
     // conv's tap 0) right after its last use, and the operand fragments of the next step are read during the current one.
     // (A last, discarded fragment read follows the final step; the stream is padded by one conv for the prefetch.)
-    auto conv = [&](int dil) __attribute__((always_inline)) {
+    auto conv = [&](f32x16 (&acc)[NTW], int dil) __attribute__((always_inline)) {  // (accumulates into the given register set)
         if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_CONV);
         load_b(Bv[0], 0, -center * dil);
         for (int j = 0; j < K; ++j) {
@@ -288,6 +288,11 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
         write_p(R, SCH::XS);
         __syncthreads();
     }
+    // R is carried in SCALED form between pairs: after a pair's second conv the accumulator IS the new residual times rs = XS * wsc
+    // of that conv, and it stays in its registers -- the next second conv starts from fma(R, s2 / rs, b2 * s2) in place, the operand
+    // conversion takes XS / rs as its factor.  Every factor is a power of two, so each value equals the unscaled formulation's
+    // ((b2 + R) * s2, R = acc / s2) bit for bit; per pair it saves 24 packed multiplies and 24 packed adds of ~560 VALU instructions.
+    float rs = 1.f;  // scale of R (1 after the load)
     for (int mm = 0; mm < p.n_conv; mm += 2) {
         const int m = br * p.n_conv + mm;  // (pair kernels: one branch, m = mm)
         float bv[16];
@@ -298,31 +303,44 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? bv[r] * s1 : bv[r];
-        conv(p.dil[m]);
+        conv(acc, p.dil[m]);
         __syncthreads();  // every wave is done reading P
         write_p(acc, 1.f / p.wsc[m]);  // P = split(lrelu(h)), masked: acc / s1 * XS
         __syncthreads();
-        // R = conv_1(P) + b2 + R
+        // R = conv_1(P) + b2 + R, accumulated IN R's registers
         bias_rows(p.bias[m + 1], bv);
+        if constexpr (SCH::XS != 1.f) {
+            const float ratio = s2 / rs;
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+            for (int r = 0; r < 16; ++r) bv[r] = bv[r] * s2;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? (bv[r] + R[nt][r]) * s2 : bv[r] + R[nt][r];
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) R[nt][r] = __builtin_fmaf(R[nt][r], ratio, bv[r]);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) R[nt][r] = bv[r] + R[nt][r];
+        }
         // (the residual rides in the accumulator: keeping R live across this conv costs 48 VGPRs, i.e. the third workgroup per
         //  CU or spills -- measured 4.8 -> 8.1 ms per step; in the vocoder |x| ~ |conv sum|, so folding costs no accuracy)
-        conv(p.dil[m + 1]);
-        const float i2 = 1.f / s2;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) R[nt][r] = (SCH::XS != 1.f) ? acc[nt][r] * i2 : acc[nt][r];
+        conv(R, p.dil[m + 1]);
+        rs = (SCH::XS != 1.f) ? s2 : 1.f;
         // (columns outside the sequence now hold garbage in R: they never feed a valid column -- write_p zeroes their operand slots --
         //  and the final store drops them or leaves them in the row's unspecified tail)
         if (mm + 2 < p.n_conv) {
             __syncthreads();
-            write_p(R, SCH::XS);
+            write_p(R, SCH::XS / rs);
             __syncthreads();
         }
+    }
+    if constexpr (SCH::XS != 1.f) {  // back to the plain residual for the branch sum / the store
+        const float inv = 1.f / rs;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) R[nt][r] = R[nt][r] * inv;
     }
     if constexpr (MRF) {  // xs = rb_0(x), then xs += rb_j(x): the same adds, in the same order, as the per-branch launches' epilogues
 #pragma unroll

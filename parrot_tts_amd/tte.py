@@ -110,9 +110,17 @@ class Parrot(nn.Module):
         # torch's load_state_dict recurses through _load_from_state_dict and never calls a CHILD's load_state_dict
         # override, so a reload through any wrapper (LitParrot, nn.Sequential ...) is caught here: the post hook runs
         # for every module of the tree, and _current_handle() also compares the parameters' version fingerprint.
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+        self._fell_back = False  # the override above was set by the range-safe fallback (not by the caller)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._on_load())
 
     # ---- parameter bookkeeping ----------------------------------------------------------------
+    def _on_load(self):
+        """New weights: drop the packed handle -- and a bf16x6 override that the range-safe fallback set for the OLD weights (the new
+        checkpoint gets the default scheme and its own first-forward probe)."""
+        self._invalidate()
+        if self._fell_back:
+            self._precision_override, self._fell_back = None, False
+
     def _invalidate(self):
         if self._handle is not None:
             _lib.lib().parrot_tte_destroy(self._handle)
@@ -191,6 +199,7 @@ class Parrot(nn.Module):
         warnings.warn(f"parrot_tts_amd TTE: {why}: an activation left the fp16x3 scheme's range (|x| < 8190); rebuilding the handle in "
                       "bf16x6 (fp32's range) for this and all later batches.", RuntimeWarning, stacklevel=3)
         self._precision_override = PREC_BF16X6
+        self._fell_back = True
         self._invalidate()
         return True
 

@@ -153,9 +153,17 @@ class CodeGenerator(nn.Module):
         self._probe_pending = False
         # a reload through a parent module never reaches a child's load_state_dict override: invalidate from the post
         # hook torch runs for every module of the tree, and compare the parameter fingerprint before each forward
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+        self._fell_back = False  # the override above was set by the range-safe fallback (not by the caller)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._on_load())
 
     # ---- parameter bookkeeping ----------------------------------------------------------------
+    def _on_load(self):
+        """New weights: drop the packed handle -- and a bf16x6 override that the range-safe fallback set for the OLD weights (the new
+        checkpoint gets the default scheme and its own first-forward probe)."""
+        self._invalidate()
+        if self._fell_back:
+            self._precision_override, self._fell_back = None, False
+
     def _invalidate(self):
         if self._handle is not None:
             _lib.lib().parrot_voc_destroy(self._handle)
@@ -276,6 +284,7 @@ class CodeGenerator(nn.Module):
                       "in bf16x6 (fp32's range, ~1.5x slower) for this and all later batches. CodeGenerator.activation_headroom() "
                       "shows the per-stage maxima.", RuntimeWarning, stacklevel=3)
         self._precision_override = PREC_BF16X6
+        self._fell_back = True
         self._invalidate()
         return True
 

@@ -123,3 +123,57 @@ def test_rccl_primitives_of_the_gather_path_single_rank():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank_check.py")], capture_output=True, text=True, cwd=ROOT,
                          env=dict(os.environ, GRAFT_REPO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=600)
     assert out.returncode == 0 and "rccl single-rank primitives ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def _worker8(rank, world, port, out_dir):
+    """Eight ranks on one GPU (gloo carries the collective): 37 ragged rows -- data-dependent durations, so every shard has its
+    own L and every row its own sample count -- sharded 5 / 5 / 5 / 5 / 5 / 4 / 4 / 4, synthesised per shard by the HIP pipeline (padded-batch
+    and row-exact TTE), gathered with gather_waveforms(n_samples=...)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PARROT_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    from parrot_tts_amd import dist as pdist, synth
+    from parrot_tts_amd.pipeline import SynthesisPipeline
+    r, w, local = pdist.init_from_env("nccl")
+    dev = pdist.local_device(local)
+    torch.cuda.set_device(dev)
+    parrot, gen, vocab, n_spk = _models(os.path.join(out_dir, f"tte{rank}"))
+    parrot, gen = parrot.to(dev), gen.to(dev)
+    full = synth.synth_tte_batch(37, 17, vocab, n_spk, seed=11, ragged=True)
+    for row_exact in (False, True):
+        pipe = SynthesisPipeline(parrot, gen, row_exact=row_exact)
+        mine = {k: v.to(dev) for k, v in pdist.shard_batch(full, r, w).items()}
+        out = pipe(mine)
+        got = pdist.gather_waveforms(out["wav"], dst=0, n_samples=out["n_samples"])
+        if r == 0:
+            wav_all, n_all = got
+            assert wav_all.shape[0] == 37 and n_all.numel() == 37
+            at = 0
+            lens_seen = set()
+            for rr in range(w):
+                shard = {k: v.to(dev) for k, v in pdist.shard_batch(full, rr, w).items()}
+                ref = pipe(shard)
+                lens_seen.add(int(ref["wav"].shape[-1]))
+                for b in range(ref["wav"].shape[0]):
+                    n = int(ref["n_samples"][b])
+                    assert int(n_all[at]) == n
+                    assert torch.equal(wav_all[at, :, :n], ref["wav"][b, :, :n]), (row_exact, rr, b)
+                    at += 1
+            assert at == 37 and len(lens_seen) > 1  # the shards really had different lengths
+            if row_exact:  # row-exact results do not depend on the sharding at all: one 37-row batch gives the same rows
+                whole = pipe({k: v.to(dev) for k, v in full.items() if torch.is_tensor(v)})
+                for b in range(37):
+                    n = int(whole["n_samples"][b])
+                    assert int(n_all[b]) == n and torch.equal(wav_all[b, :, :n], whole["wav"][b, :, :n]), b
+        else:
+            assert got is None
+        torch.distributed.barrier()
+    if r == 0:
+        open(os.path.join(out_dir, "ok8"), "w").write("ok")
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_ranks_on_one_gpu_ragged_pipeline_and_gather(tmp_path):
+    """a ragged (data-dependent duration) 8-rank run through the HIP pipeline + gather_waveforms(n_samples=...)."""
+    mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert (tmp_path / "ok8").read_text() == "ok"

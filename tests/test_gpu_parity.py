@@ -341,8 +341,13 @@ def test_vocoder_matches_reference_golden(golden_dir, name, prec, fused):
         hip_err = float(np.abs(y.cpu().numpy().astype(np.float64) - ref64).max())
         _report(test="vocoder_golden", name=name, precision=prec, fused=int(fused), wav_max_abs_err=err, hip_vs_fp64=hip_err,
                 reference_fp32_vs_fp64=ref_err)
-        assert hip_err <= 3.0 * ref_err, f"HIP vs fp64 {hip_err} > 3 x reference fp32 vs fp64 {ref_err}"
-        assert err <= 4.0 * ref_err, f"waveform max-abs error {err} vs the fp32 golden (reference's own error {ref_err})"
+        # numeric bounds (round 5): the reference's own fp32 run is 1.04e-4 from exact arithmetic on this case; the HIP path measures
+        # 1.3-1.6e-4 (default scheme) ... 2.3e-4 (exact-fp32 MFMA: one product per rounding step), i.e. 1.2-2.2x -- spread evenly over
+        # the stages (tests/test_gpu_round5.py::test_hot_golden_error_by_stage: 1.1-1.3x the reference's error after EVERY stage, no
+        # single layer stands out) and amplified by pre-tanh magnitudes of ~120.
+        assert ref_err <= 1.5e-4, ref_err
+        assert hip_err <= 3.0e-4, f"HIP vs fp64 {hip_err} (reference fp32 vs fp64 {ref_err})"
+        assert err <= 4.0e-4, f"waveform max-abs error {err} vs the fp32 golden (reference's own error {ref_err})"
     else:
         _report(test="vocoder_golden", name=name, precision=prec, fused=int(fused), wav_max_abs_err=err)
         assert err <= 5e-5, f"waveform max-abs error {err}"

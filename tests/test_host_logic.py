@@ -203,8 +203,9 @@ def test_profile_kernel_names_fold_to_bench_rows():
     cases = {"conv_split_kernel<parrot::SchF16x3, 2, 2, 2, 2, 2, 11, 1>": "conv_split_kernel<SchF16x3,2,2,2,2,2>",
              "conv_split_kernel<parrot::SchF16x3, 4, 1, 1, 2, 3, 1, 4, true>": "conv_split_kernel<SchF16x3,4,1,1,2,3>",
              "conv_split_kernel<parrot::SchF16x3, 1, 4, 1, 4, 2, 3, 1>": "conv_split_kernel<SchF16x3,1,4,1,4,2>",
-             "resblock_split_kernel<parrot::SchF16x3, 4>": "resblock_split_kernel<SchF16x3,4>",
-             "resblock_split_kernel<parrot::SchF16x3, 16>": "resblock_split_kernel<SchF16x3,16>",
+             "resblock_split_kernel<parrot::SchF16x3, 4, 0, false>": "resblock_split_kernel<SchF16x3,4>",
+             "resblock_split_kernel<parrot::SchF16x3, 16, 0, false>": "resblock_split_kernel<SchF16x3,16>",
+             "resblock_split_kernel<parrot::SchF16x3, 2, 8, true>": "resblock_split_kernel<SchF16x3,2,8,MRF>",
              "conv_split16_kernel<parrot::SchF16x3, 2, 2, 4, 5, 11, 2>": "conv_split16_kernel<SchF16x3,2,2,4,5>",
              "resblock16_split_kernel<parrot::SchF16x3>": "resblock16_split_kernel<SchF16x3>",
              "conv1_valu_kernel<7>": "conv1_valu_kernel", "conv1_valu7_vec_kernel": "conv1_valu_kernel", "convt_valu_kernel<16, 4, 2, 1>": "convt_valu_kernel<16,4,2,1>",

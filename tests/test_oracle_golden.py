@@ -159,7 +159,10 @@ def test_vocoder_oracle_matches_reference(golden_dir, name, tmp_path):
         assert int(np.abs(O.to_int16(y.squeeze(1)).astype(np.int32) - z["wav_int16"].astype(np.int32)).max()) <= 1
     for k in z.files:
         if k.startswith("stage_"):
-            assert np.array_equal(st[k[6:]].numpy(), z[k]), k
+            if pinned_by == "golden":
+                assert np.array_equal(st[k[6:]].numpy(), z[k]), k
+            else:  # (a host that sums the fp32 convs in another order than the golden's: the same evaluation-order noise per stage)
+                assert float(np.abs(st[k[6:]].numpy() - z[k]).max()) <= 2e-5 * max(1.0, float(np.abs(z[k]).max())), k
     if "wav_fp64" in z.files:  # the reference's own fp32 round-off at realistic scale
         assert np.abs(z["wav"] - z["wav_fp64"]).max() < 5e-5
 

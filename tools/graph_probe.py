@@ -31,9 +31,9 @@ wav = torch.empty((B, 1, L * 320), device=dev)
 spk2 = batch["speaker"].reshape(-1).contiguous()
 
 def enc():
-    _lib.check(lib.parrot_tte_encode(H, dptr(phones), dptr(valid), dptr(spk), B, S, dptr(log_dur), dptr(dur), dptr(lens), dptr(state), state.numel(), dptr(ws_e), ws_e.numel(), stream_ptr(dev)))
+    _lib.check(lib.parrot_tte_encode(H, dptr(phones), dptr(valid), dptr(spk), None, B, S, dptr(log_dur), dptr(dur), dptr(lens), dptr(state), state.numel(), dptr(ws_e), ws_e.numel(), stream_ptr(dev)))
 def dec():
-    _lib.check(lib.parrot_tte_decode(H, B, S, L, dptr(ids), dptr(tgt), None, dptr(state), state.numel(), dptr(ws_d), ws_d.numel(), stream_ptr(dev)))
+    _lib.check(lib.parrot_tte_decode(H, B, S, L, 0, dptr(ids), dptr(tgt), None, dptr(state), state.numel(), dptr(ws_d), ws_d.numel(), stream_ptr(dev)))
 def voc():
     _lib.check(lib.parrot_voc_forward(VH, dptr(ids), dptr(spk2), None, B, L, dptr(wav), None, dptr(ws_v), ws_v.numel(), stream_ptr(dev)))
 

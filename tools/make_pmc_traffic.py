@@ -22,6 +22,9 @@ def norm(name: str) -> str:
     m = re.match(r"(conv_split16_kernel<Sch\w+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
     if m:
         return m.group(1) + ">"
+    m = re.match(r"resblock_split_kernel<(Sch\w+),(\d+),(\d+),(true|false)>", name)  # (scheme, chunks, column groups, whole-MRF)
+    if m:
+        return f"resblock_split_kernel<{m.group(1)},{m.group(2)},{m.group(3)},MRF>" if m.group(4) == "true" else f"resblock_split_kernel<{m.group(1)},{m.group(2)}>"
     if name == "conv1_valu7_vec_kernel":
         return "conv1_valu_kernel"
     return re.sub(r"^(conv1_valu_kernel)<\d+>$", r"\1", name)  # instantiations that share one bench.py row
@@ -38,20 +41,40 @@ def load(path: str, col: str):
     return {k: tot[k] / calls[k] for k in tot}
 
 
+def load_busy(path: str):
+    """MFMA-busy fraction per kernel from the SQ pass: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), launches summed."""
+    if not os.path.exists(path):
+        return {}
+    mf, cu = {}, {}
+    for r in csv.DictReader(open(path)):
+        if not r.get("SQ_VALU_MFMA_BUSY_CYCLES_sum") or not r.get("SQ_BUSY_CU_CYCLES_sum"):
+            continue
+        k = norm(r["kernel"])
+        mf[k] = mf.get(k, 0.0) + float(r["SQ_VALU_MFMA_BUSY_CYCLES_sum"])
+        cu[k] = cu.get(k, 0.0) + float(r["SQ_BUSY_CU_CYCLES_sum"])
+    return {k: mf[k] / (4.0 * cu[k]) for k in mf if cu[k] > 0}
+
+
 def main():
     tag, cmd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
     fetch = load(os.path.join(ROOT, "profiles", f"{tag}_bench_fetch.csv"), "FETCH_SIZE")
     write = load(os.path.join(ROOT, "profiles", f"{tag}_bench_write.csv"), "WRITE_SIZE")
+    busy = load_busy(os.path.join(ROOT, "profiles", f"{tag}_bench_sq.csv"))
+    box_file = os.path.join(ROOT, "profiles", f"{tag}_box.txt")
+    box = open(box_file).read().strip() if os.path.exists(box_file) else None
     out = {"_comment": f"HBM bytes per launch, rocprofv3 PMC passes of `{cmd}`. FETCH_SIZE / WRITE_SIZE in separate passes "
                        f"(profiles/{tag}_bench_fetch.csv, {tag}_bench_write.csv; KiB per launch averaged over all launches of the kernel, "
                        "tap-count instantiations of one tile folded); FETCH_SIZE doubled per the gfx950 calibration "
-                       "(profiles/r01_calibration_copy_*.csv: 0.500 x bytes), WRITE_SIZE as is (1.000 x bytes)."}
+                       "(profiles/r01_calibration_copy_*.csv: 0.500 x bytes), WRITE_SIZE as is (1.000 x bytes).  mfma_busy: "
+                       f"SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the SQ pass of the same command (profiles/{tag}_bench_sq.csv).",
+           "_box": box}
     for k in sorted(fetch, key=lambda k: -fetch[k]):
         if "kernel" not in k:
             continue
         w = write.get(k, 0.0)
         out[k] = {"fetch_kib_raw": round(fetch[k], 1), "write_kib_raw": round(w, 1),
-                  "hbm_bytes_per_launch": int(round((2.0 * fetch[k] + w) * 1024))}
+                  "hbm_bytes_per_launch": int(round((2.0 * fetch[k] + w) * 1024)),
+                  "mfma_busy": (round(busy[k], 4) if k in busy else None)}
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1)[:1500])
 

@@ -7,6 +7,8 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# which box these counters come from (bench.py prints it beside roofline.traffic)
+{ hostname; rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id" | head -1; rocminfo 2>/dev/null | grep -m1 -i "marketing name.*MI3"; } | tr '\n' ' ' | sed 's/  */ /g' > "$OUT/${TAG}_box.txt"
 CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt"
 cd /tmp
 run() {  # name, rocprofv3 args...
