@@ -46,7 +46,7 @@ TILE_NAMES = ["conv_mfma_kernel<2,2,2,2,16,3>", "conv_mfma_kernel<1,4,2,2,16,3>"
               "conv_split16_kernel<SCH,2,2,2,4>",  # the 64-row tile
               "(unused)", "conv_split16_kernel<SCH,2,2,4,5>",
               "resblock_split_kernel<SCH,4>", "resblock_split_kernel<SCH,8>", "resblock_split_kernel<SCH,16>",
-              "resblock_split_kernel<SCH,2,8,MRF>", "resblock_split_kernel<SCH,4,4,MRF>"]  # whole-MRF launches (32 / 64 channels)
+              "resblock_split_kernel<SCH,2,8,MRF>"]  # the whole-MRF launch of the 32-channel stage
 SCHEMES = {"f16x3": ("SchF16x3", 3), "bf16x6": ("SchBf16x6", 6), "bf16": ("SchBf16", 1), "f16": ("SchF16", 1), "f32": ("-", 1)}
 MFMA16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split scheme spends 3 (f16x3) or 6 (bf16x6) MFMA FMAs per algorithmic fp32 FMA
 

@@ -669,11 +669,8 @@ struct parrot_voc {
     std::vector<uint16_t*> rb_stream;  // per (stage, kernel): concatenated split weight stream of the block (or null)
     std::vector<float> rb_wsc;         // per resblock conv: weight scale inside that stream (fp16 schemes; else 1)
     std::vector<size_t> rb_conv_halves;  // 16-bit words per conv in that stream
-    // whole-MRF launches (resblock_split.h, MRF instantiations): per (stage, kernel) the branch's stream in the 32x32x16 layout --
-    // rb_stream's where it exists, else packed for this path (64 channels, k = 11: its layer plans are packed for conv_split16);
-    // mrf_ok[stage]: every branch of the stage has one and the window survives the widest branch's reach
-    std::vector<uint16_t*> mrf_stream;
-    std::vector<uint16_t*> mrf_owned;
+    // whole-MRF launches (resblock_split.h, MRF instantiation): mrf_ok[stage] = every branch of the stage has a pair-kernel weight
+    // stream (rb_stream) and the window survives the widest branch's reach
     std::vector<char> mrf_ok;
     int up_total = 1;
     bool odd_stage = false;            // some stage has odd kernel_size - rate: T_out = T u + 1 there (no constant hop)
@@ -729,8 +726,6 @@ struct parrot_voc {
         if (ev_lane_fork) (void)hipEventDestroy(ev_lane_fork);
         for (hipEvent_t e : ev_lane_join)
             if (e) (void)hipEventDestroy(e);
-        for (uint16_t* q : mrf_owned)
-            if (q) (void)hipFree(q);
         for (uint16_t* q : rb_stream)
             if (q) (void)hipFree(q);
         if (dict) (void)hipFree(dict);
@@ -907,58 +902,24 @@ static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const 
                 HIP_TRY(hipMemcpy(st, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             }
         }
-    // whole-MRF launches for the 32- and 64-channel stages (PARROT_MRF_FUSED, default on): all branches of a stage in one kernel
-    v->mrf_stream.assign((size_t)cfg->n_stages * cfg->n_kernels, nullptr);
+    // whole-MRF launches for the 32-channel stage (PARROT_MRF_FUSED, default on): all branches of a stage in one kernel, on the pair
+    // kernels' own weight streams -- bit-identical to the per-branch launches and no slower (2.27 vs 2.31 ms per step at B = 64; 14 -> 2
+    // passes over the stage's activations).  (64 channels were built and measured slower: profiles/r05b_mrf_ab.jsonl.)
     v->mrf_ok.assign((size_t)cfg->n_stages, 0);
     {
-        // PARROT_MRF_FUSED: 1 (default) the 32-channel stage, where the launch is bit-identical to the pair kernels' and no slower
-        // (2.27 vs 2.31 ms per step at B = 64, 14 -> 2 passes over the stage's activations); 2 also the 64-channel stage (measured
-        // SLOWER: 4.92 vs 4.27 ms -- a 384-column window keeps 69 % of its columns, profiles/r05b_*); 0 off
-        static const int want = [] { const char* e = getenv("PARROT_MRF_FUSED"); return e ? atoi(e) : 1; }();
-        for (int i = 0; i < cfg->n_stages && want > 0 && v->fused != 0 && v->scheme >= 1 && resblock_mrf_scheme(v->scheme); ++i) {
+        static const bool want = [] { const char* e = getenv("PARROT_MRF_FUSED"); return !e || atoi(e) != 0; }();
+        for (int i = 0; i < cfg->n_stages && want && v->fused != 0 && v->scheme >= 1 && resblock_mrf_scheme(v->scheme); ++i) {
             const int C = v->chan(i);
             if (cfg->resblock_type != 1 || !resblock_mrf_has(C) || per_rb > RBS_MAX_CONVS || cfg->n_kernels > RBS_MAX_BRANCH) continue;
-            if (C == 64 && want < 2) continue;
             bool ok = true;
             int Hmax = 0;
-            for (int j = 0; j < cfg->n_kernels && ok; ++j) {
+            for (int j = 0; j < cfg->n_kernels; ++j) {
                 const int rk = cfg->resblock_kernel_sizes[j];
                 const int base = (i * cfg->n_kernels + j) * per_rb;
-                if (!(rk & 1)) { ok = false; break; }
+                ok = ok && (rk & 1) && v->rb_stream[(size_t)i * cfg->n_kernels + j];
                 int H = 0;
                 for (int q = 0; q < per_rb; ++q) H += (rk - 1) / 2 * v->rb[base + q]->dil;
                 Hmax = std::max(Hmax, H);
-                if (v->rb_stream[(size_t)i * cfg->n_kernels + j]) {
-                    v->mrf_stream[(size_t)i * cfg->n_kernels + j] = v->rb_stream[(size_t)i * cfg->n_kernels + j];
-                    continue;
-                }
-                // pack [conv][32-row tile][chunk * k + tap][piece][lane][8 x 16 bit] (+ one conv of padding for the prefetch past the end)
-                const int steps = (C / 32) * (C / 16) * rk;
-                const size_t step_h = (size_t)NP * 512;
-                std::vector<uint16_t> pk(((size_t)(per_rb + 1) * steps) * step_h, 0);
-                for (int q = 0; q <= per_rb; ++q) {
-                    const int qq = q < per_rb ? q : 0;
-                    const float* wq = w->rb_w[base + qq];  // (C, C, rk)
-                    const float wsc = scheme_is_f16(v->scheme) ? f16_weight_scale(wq, (size_t)C * C * rk) : 1.f;
-                    if (q < per_rb) v->rb_wsc[base + q] = wsc;
-                    for (int mt = 0; mt < C / 32; ++mt)
-                        for (int ch = 0; ch < C / 16; ++ch)
-                            for (int tap = 0; tap < rk; ++tap) {
-                                uint16_t* g = pk.data() + ((size_t)q * steps + (size_t)mt * (C / 16) * rk + (size_t)ch * rk + tap) * step_h;
-                                for (int lane = 0; lane < 64; ++lane)
-                                    for (int e = 0; e < 8; ++e) {
-                                        const int row = mt * 32 + (lane & 31), cin = ch * 16 + 8 * (lane >> 5) + e;
-                                        uint16_t hh[3];
-                                        split_weight(wq[((size_t)row * C + cin) * rk + tap], v->scheme, wsc, hh);
-                                        for (int pc = 0; pc < NP; ++pc) g[pc * 512 + lane * 8 + e] = hh[pc];
-                                    }
-                            }
-                }
-                uint16_t* st = nullptr;
-                HIP_TRY(hipMalloc((void**)&st, pk.size() * sizeof(uint16_t)));
-                v->mrf_owned.push_back(st);
-                HIP_TRY(hipMemcpy(st, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-                v->mrf_stream[(size_t)i * cfg->n_kernels + j] = st;
             }
             v->mrf_ok[i] = ok && rbs_mrf_window(C) - 2 * Hmax >= rbs_mrf_window(C) / 2;
         }
@@ -1085,10 +1046,12 @@ static int resblock_split_launch(const parrot_voc* v, int stage, int j, const fl
         p.y = last ? y : ((n_launch & 1) ? tmp_b : tmp_a);
         p.wstream = stream + (size_t)m0 * v->rb_conv_halves[(size_t)stage * c.n_kernels + j];
         p.n_conv = m1 - m0;
+        p.early = 1;
         for (int q = m0; q < m1; ++q) {
             p.bias[q - m0] = v->rb[base + q]->bias;
             p.wsc[q - m0] = v->rb_wsc[base + q];
             p.dil[q - m0] = v->rb[base + q]->dil;
+            if ((k - 1) / 2 * v->rb[base + q]->dil > 32) p.early = 0;
         }
         p.T = T; p.B = B; p.H = H; p.k = k;
         p.TT = W - 2 * H;
@@ -1124,7 +1087,7 @@ static int mrf_tile_cols(const parrot_voc* v, int stage) {
     }
     return std::max(1, rbs_mrf_window(v->chan(stage)) - 2 * Hmax);
 }
-// Whole-MRF launch of a 32- / 64-channel stage (resblock_split.h, MRF instantiations): y = sum_j ResBlock_j(x) / n_kernels.
+// Whole-MRF launch of the 32-channel stage (resblock_split.h, MRF instantiations): y = sum_j ResBlock_j(x) / n_kernels.
 static int mrf_split_launch(const parrot_voc* v, int stage, const float* x, float* y, int B, int T, hipStream_t s, const int32_t* row_len,
                             int row_len_mul, int row_len_add) {
     const parrot_voc_cfg& c = v->cfg;
@@ -1133,11 +1096,11 @@ static int mrf_split_launch(const parrot_voc* v, int stage, const float* x, floa
     ResblockSplitParams p{};
     p.x = x; p.y = y;
     p.n_conv = per_rb; p.n_branch = nk;
-    int Hmax = 0;
+    int Hmax = 0, early = 1;
     double macs = 0;
     for (int j = 0; j < nk; ++j) {
         const int base = (stage * nk + j) * per_rb, k = c.resblock_kernel_sizes[j];
-        p.bstream[j] = v->mrf_stream[(size_t)stage * nk + j];
+        p.bstream[j] = v->rb_stream[(size_t)stage * nk + j];
         p.bk[j] = k;
         int H = 0;
         for (int q = 0; q < per_rb; ++q) {
@@ -1145,11 +1108,13 @@ static int mrf_split_launch(const parrot_voc* v, int stage, const float* x, floa
             p.wsc[j * per_rb + q] = v->rb_wsc[base + q];
             p.dil[j * per_rb + q] = v->rb[base + q]->dil;
             H += (k - 1) / 2 * v->rb[base + q]->dil;
+            if ((k - 1) / 2 * v->rb[base + q]->dil > 32) early = 0;
         }
         Hmax = std::max(Hmax, H);
         macs += (double)B * C * C * k * T * per_rb;
     }
     p.k = p.bk[0];
+    p.early = early;
     p.T = T; p.B = B; p.H = Hmax;
     p.TT = W - 2 * Hmax;
     p.tiles = (T + p.TT - 1) / p.TT;
@@ -1157,7 +1122,7 @@ static int mrf_split_launch(const parrot_voc* v, int stage, const float* x, floa
     p.div = (float)nk; p.slope = 0.1f;
     p.row_len = row_len; p.row_len_mul = row_len_mul; p.row_len_add = row_len_add;
     ProfRec rec{};
-    if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + (C == 32 ? 16 : 17), 2.0 * macs, 4.0 * B * (double)C * T * 2, s));
+    if (g_prof_on) TRY(prof_open(rec, NUM_TILE_CFGS + 16, 2.0 * macs, 4.0 * B * (double)C * T * 2, s));
     HIP_TRY(launch_mrf_split(v->scheme, C, p, s));
     if (g_prof_on) TRY(prof_close(rec, s));
     return PARROT_OK;

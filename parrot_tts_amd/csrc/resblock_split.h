@@ -34,12 +34,9 @@ constexpr int RBS_MAX_CONVS = 8;    // convs of one ResBlock (pairs x 2)
 constexpr int RBS_MAX_BRANCH = 4;   // MRF branches of a stage (PARROT_MAX_KERNELS)
 constexpr int RBS_MAX_ALL = RBS_MAX_CONVS * RBS_MAX_BRANCH;
 
-// experiment switches (tools/build_exp.sh): wave priority of the MFMA phase / of the conversion phase (0 = leave it alone)
-#ifndef RBS_PRIO_CONV
-#define RBS_PRIO_CONV 0
-#endif
-#ifndef RBS_PRIO_WP
-#define RBS_PRIO_WP 0
+// 1 (default): a wave converts the columns no other wave reads BEFORE the barrier that ends a conv (see write_p); 0: round-4 order
+#ifndef RBS_EARLY_INNER
+#define RBS_EARLY_INNER 1
 #endif
 
 struct ResblockSplitParams {
@@ -53,6 +50,7 @@ struct ResblockSplitParams {
     int k;                    // taps of every conv of the block
     // whole-MRF launches (the MRF instantiations): every ResBlock branch of the stage in ONE launch -- conv m of branch j is entry
     // j * n_conv + m of the arrays above, branch j walks its own weight stream with its own tap count; y = sum_j branch_j(x) / div
+    int early;                // every conv's reach (k - 1) / 2 * dil is <= 32 columns: the inner tiles may be rewritten before the barrier (write_p)
     int n_branch;
     const uint16_t* bstream[RBS_MAX_BRANCH];
     int bk[RBS_MAX_BRANCH];
@@ -77,15 +75,18 @@ constexpr int RBS_W = 384;  // 32-channel window (the 64-channel kernel uses hal
 // WN = column groups (waves side by side; 0 = the pair kernels' own: 4 waves per workgroup up to 128 channels).  MRF = whole-stage
 // launches: all ResBlock branches of an MRF stage per window, the branch sum in registers (x is read once per branch -- from L2
 // after the first -- and y written ONCE per stage instead of three launches that each re-read x and read-modify-write the sum).
-// The MRF instantiations run 8 waves on a twice-as-wide window (32 channels: 768 columns, 64 channels: 384; 96 KiB of LDS, one
-// workgroup per CU, <= 256 VGPRs): 18 convs per window amortise the window's load / store, which a single resident workgroup
-// cannot hide behind another's MFMAs, and the total reach of the k = 11 branch (60 columns) still leaves 84 % / 69 % of a window.
+// The MRF instantiation (32 channels) runs 8 waves on a twice-as-wide window (768 columns; 96 KiB of LDS, one workgroup per CU,
+// <= 256 VGPRs): 18 convs per window amortise the window's load / store, which a single resident workgroup cannot hide behind
+// another's MFMAs, and the total reach of the k = 11 branch (60 columns) still leaves 84 % of a window.  (The 64-channel
+// instantiation -- 384 columns, 69 % -- was built and measured slower than pair launches + layer kernels: profiles/r05b_mrf_ab.jsonl.)
 constexpr int rbs_default_wn(int nch) { return (nch / 2 >= 4) ? 1 : 4 / (nch / 2); }
 template <class SCH, int NCH, int WN = 0, bool MRF = false>
 __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
                              ((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64 == 512) ? 1 : (SCH::NP == 3 ? 2 : 3)) void resblock_split_kernel(const ResblockSplitParams p) {
     constexpr int NPC = SCH::NP, NTERM = SCH::NT, STEP_BYTES = SCH::NP * 1024;
     constexpr int C = 16 * NCH, WAVES_M = NCH / 2, WAVES_N = WN ? WN : rbs_default_wn(NCH), NTW = 3, W = WAVES_N * NTW * 32;
+    // (with several row tiles the waves of a column group read each other's channels: 32 channels only)
+    const bool early = (WAVES_M == 1) && RBS_EARLY_INNER && __builtin_amdgcn_readfirstlane(p.early) != 0;
     int K = MRF ? p.bk[0] : p.k;
     // operand buffer: [piece][chunk][octet][col][8 channels]: 16 bytes per (column, octet), columns contiguous -- both the
     // 16-byte stores of write_p and the ds_read_b128 fragment reads at any tap shift walk consecutive addresses across lanes
@@ -136,10 +137,13 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
     // ---- accumulator tile -> operand buffer: (leaky ReLU,) sequence mask, 3-way split, two 8-byte stores per
     //      (tile, chunk, piece, row group): rows 8q+4g+{0..3} of this half are channels 16 (2 wm + q) + 8g + 4 half + {0..3}
     // `mul`: (power-of-two) factor taking v to the operand scale XS (v may be a scaled accumulator)
-    auto write_p = [&](const f32x16 (&v)[NTW], float mul) __attribute__((always_inline)) {
-        if constexpr (RBS_PRIO_WP != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_WP);
+    // `part`: 0 = every tile; 1 = the INNER tile only (columns 32..63 of the wave's 96: with one row tile per workgroup -- 32 channels --
+    // no other wave reads them, every conv's reach being <= 25 columns, so they may be rewritten as soon as THIS wave has finished
+    // its conv, before the barrier: a wave that would idle at the barrier converts a third of its tile instead); 2 = the outer tiles
+    auto write_p = [&](const f32x16 (&v)[NTW], float mul, int part = 0) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
+            if (part != 0 && (nt == 1) != (part == 1)) continue;
             const float m2 = (SCH::XS != 1.f) ? mul * p.slope : p.slope;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -170,7 +174,7 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
         if (edge) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
-                if (!tok[nt]) {
+                if (!tok[nt] && (part == 0 || (nt == 1) == (part == 1))) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -178,7 +182,6 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
                             *reinterpret_cast<uint4*>(smem_raw + (2 * wm + q) * CH_BYTES + half * OCT_BYTES + col[nt] * 16 + pc * PIECE_BYTES) = uint4{0u, 0u, 0u, 0u};
                 }
         }
-        if constexpr (RBS_PRIO_WP != 0) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- weights: one buffer descriptor, per-lane constant offset, scalar step offset ----------------------------
@@ -221,7 +224,6 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
     // conv's tap 0) right after its last use, and the operand fragments of the next step are read during the current one.
     // (A last, discarded fragment read follows the final step; the stream is padded by one conv for the prefetch.)
     auto conv = [&](f32x16 (&acc)[NTW], int dil) __attribute__((always_inline)) {  // (accumulates into the given register set)
-        if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_CONV);
         load_b(Bv[0], 0, -center * dil);
         for (int j = 0; j < K; ++j) {
             const int shift = (j - center) * dil;
@@ -262,7 +264,6 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
             __builtin_amdgcn_sched_barrier(0);
         }
         gbase += conv_steps;
-        if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(0);
     };
     auto bias_rows = [&](const float* __restrict__ bias, float (&bv)[16]) __attribute__((always_inline)) {
 #pragma unroll
@@ -304,8 +305,9 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? bv[r] * s1 : bv[r];
         conv(acc, p.dil[m]);
+        if (early) write_p(acc, 1.f / p.wsc[m], 1);
         __syncthreads();  // every wave is done reading P
-        write_p(acc, 1.f / p.wsc[m]);  // P = split(lrelu(h)), masked: acc / s1 * XS
+        write_p(acc, 1.f / p.wsc[m], early ? 2 : 0);  // P = split(lrelu(h)), masked: acc / s1 * XS
         __syncthreads();
         // R = conv_1(P) + b2 + R, accumulated IN R's registers
         bias_rows(p.bias[m + 1], bv);
@@ -330,8 +332,9 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
         // (columns outside the sequence now hold garbage in R: they never feed a valid column -- write_p zeroes their operand slots --
         //  and the final store drops them or leaves them in the row's unspecified tail)
         if (mm + 2 < p.n_conv) {
+            if (early) write_p(R, SCH::XS / rs, 1);
             __syncthreads();
-            write_p(R, SCH::XS / rs);
+            write_p(R, SCH::XS / rs, early ? 2 : 0);
             __syncthreads();
         }
     }
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
     const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);
     const int col0 = wave * (NT * 16) + l15;  // this lane's window column in tile 0 (tile nt adds 16 nt)
+    const bool early = RBS_EARLY_INNER && __builtin_amdgcn_readfirstlane(p.early) != 0;
 
     f32x4 R[NT], acc[NT];
     {
@@ -439,11 +443,14 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
             for (int r = 0; r < 4; ++r) R[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, r * row_bytes, 0));
         }
     }
-    auto write_p = [&](const f32x4 (&v)[NT], float mul) __attribute__((always_inline)) {
-        if constexpr (RBS_PRIO_WP != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_WP);
+    // `part`: 0 = every tile pair; 1 = the INNER pairs only (tiles 2..9 = columns 32..159 of the wave's 192: no other wave reads
+    // them, every conv's reach being <= 25 columns -- written before the barrier that ends a conv, see resblock_split_kernel);
+    // 2 = the outer pairs
+    auto write_p = [&](const f32x4 (&v)[NT], float mul, int part = 0) __attribute__((always_inline)) {
         const float m2 = (SCH::XS != 1.f) ? mul * p.slope : p.slope;
 #pragma unroll
         for (int np = 0; np < NT; np += 2) {  // tile pairs: lane groups with even g4 end up owning tile np's octet, odd ones tile np+1's
+            if (part != 0 && (np >= 2 && np < NT - 2) != (part == 1)) continue;
             unsigned qq[2][2][NPC];           // [tile of the pair][pair e][piece]
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -468,6 +475,7 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
         if (edge) {  // windows at a sequence end only: zero the operand slots of out-of-sequence columns (see resblock_split_kernel)
 #pragma unroll
             for (int np = 0; np < NT; np += 2) {
+                if (part != 0 && (np >= 2 && np < NT - 2) != (part == 1)) continue;
                 const int c = col0 + (np + (g4 & 1)) * 16;  // the column whose octet this lane stored above
                 const int t = t_base + c;
                 if (!(t >= 0 && t < Tlim)) {
@@ -477,7 +485,6 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
                 }
             }
         }
-        if constexpr (RBS_PRIO_WP != 0) __builtin_amdgcn_s_setprio(0);
     };
 
     const unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(p.wstream));
@@ -518,7 +525,6 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
         // finite -- 0 x inf = NaN -- and, with unclamped reads, columns beyond the conv's true reach may hold anything: those lanes
         // re-read tap K - 1 (inside the reach, finite wherever the output column is valid) instead of stepping one tap further out.
         const int tpd_last = tpd - (((K & 1) && (g4 >> 1)) ? dil : 0);
-        if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(RBS_PRIO_CONV);
         load_b(Bv[0], 0, S == 1 ? tpd_last : tpd);
         for (int s2 = 0; s2 < S; s2 += 2) {
 #pragma unroll
@@ -559,7 +565,6 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
             __builtin_amdgcn_sched_barrier(0);
         }
         gstep += S;
-        if constexpr (RBS_PRIO_CONV != 0) __builtin_amdgcn_s_setprio(0);
     };
 
     for (int m = 0; m < p.n_conv; m += 2) {
@@ -572,8 +577,9 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[nt][r] = bv[r];
         conv(p.dil[m]);
+        if (early) write_p(acc, 1.f / p.wsc[m], 1);
         __syncthreads();
-        write_p(acc, 1.f / p.wsc[m]);
+        write_p(acc, 1.f / p.wsc[m], early ? 2 : 0);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + 1][4 * g4 + r];
@@ -588,8 +594,9 @@ __global__ __launch_bounds__(256, SCH::NP == 3 ? 2 : 3) void resblock16_split_ke
 #pragma unroll
             for (int r = 0; r < 4; ++r) R[nt][r] = (SCH::XS != 1.f) ? fmaf(acc[nt][r], i2, R[nt][r]) : acc[nt][r] + R[nt][r];
         if (m + 2 < p.n_conv) {
+            if (early) write_p(R, SCH::XS, 1);
             __syncthreads();
-            write_p(R, SCH::XS);
+            write_p(R, SCH::XS, early ? 2 : 0);
             __syncthreads();
         }
     }
@@ -646,17 +653,17 @@ inline hipError_t launch_resblock_split_s(int C, const ResblockSplitParams& p, h
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(C == 256 ? 512 : 256), lds, s, p);
     return hipGetLastError();
 }
-// whole-MRF launches (32 / 64 channels): 8 waves, 768- / 384-column window, NP x 48 KiB of LDS
-constexpr int rbs_mrf_window(int C) { return C == 32 ? 768 : C == 64 ? 384 : 0; }
-inline bool resblock_mrf_has(int C) { return C == 32 || C == 64; }
+// whole-MRF launches (32 channels): 8 waves, 768-column window, NP x 48 KiB of LDS
+constexpr int rbs_mrf_window(int C) { return C == 32 ? 768 : 0; }
+inline bool resblock_mrf_has(int C) { return C == 32; }
 template <class SCH>
 inline hipError_t launch_mrf_split_s(int C, const ResblockSplitParams& p, hipStream_t s) {
     if (!resblock_mrf_has(C)) return hipErrorInvalidValue;
     const size_t lds = (size_t)SCH::NP * 49152;
-    auto kern = (C == 32) ? resblock_split_kernel<SCH, 2, 8, true> : resblock_split_kernel<SCH, 4, 4, true>;
-    static DynLdsOnce lds_once[2];
+    auto kern = resblock_split_kernel<SCH, 2, 8, true>;
+    static DynLdsOnce lds_once;
     {
-        hipError_t e = ensure_dyn_lds(lds_once[C == 32 ? 0 : 1], reinterpret_cast<const void*>(kern), lds);
+        hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(p.tiles * p.B), dim3(512), lds, s, p);

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # which box these counters come from (bench.py prints it beside roofline.traffic)
-{ hostname; rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id" | head -1; rocminfo 2>/dev/null | grep -m1 -i "marketing name.*MI3"; } | tr '\n' ' ' | sed 's/  */ /g' > "$OUT/${TAG}_box.txt"
+{ rocminfo 2>/dev/null | grep -m1 -i "Uuid:.*GPU-" | sed 's/^ *//'; rocminfo 2>/dev/null | grep -m1 -i "Marketing Name:.*MI3" | sed 's/^ *//'; rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id:" | head -1; } | tr '\n' ' ' | sed 's/  */ /g' > "$OUT/${TAG}_box.txt"
 CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt"
 cd /tmp
 run() {  # name, rocprofv3 args...
