@@ -295,3 +295,54 @@ def test_bf16_operating_point_snr_at_the_baseline_batch():
         worst = min(worst, _snr_db(y[r:r + 1].numpy(), ref.numpy()))
     _report(test="bf16_snr", name="b64_u256_rows_0_31_63", snr_db=worst, floor_db=35.9)
     assert worst >= 35.9, worst
+
+
+ROW_EXACT_CONFIGS = [
+    dict(enc_heads=4, dec_heads=1, kernels=[3, 3], d_model=64),      # k2 > 1: the second FFN conv takes the per-row ends too
+    dict(enc_heads=1, dec_heads=2, kernels=[5, 1], d_model=128),
+    dict(enc_heads=2, dec_heads=2, kernels=[9, 1], d_model=256),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(ROW_EXACT_CONFIGS)))
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6", "f32"])
+def test_row_exact_on_other_configs_and_precisions(tmp_path, idx, prec):
+    """Row-exact batching with other head counts / FFN kernel sizes / widths and in every parity-grade precision (the exact and
+    bf16x6 handles take the fp32-MFMA attention cores, not the flash kernel): log-durations against single-utterance oracle runs,
+    ids against them wherever durations and margins are decided, and against the HIP single-utterance runs bit for bit."""
+    nd = ROW_EXACT_CONFIGS[idx]
+    cfg = synth.small_tte_config()
+    cfg["transformer"].update(d_model=nd["d_model"], conv_kernel_sizes=nd["kernels"], max_len=1200)
+    cfg["transformer"]["encoder"]["n_head"] = nd["enc_heads"]
+    cfg["transformer"]["decoder"]["n_head"] = nd["dec_heads"]
+    cfg["duration_predictor"]["n_filter"] = nd["d_model"]
+    vocab, n_spk, B, S = 40, 3, 9, 33
+    tsd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=80 + idx)
+    ops.set_default_precision(ops.PREC_NAMES[prec])
+    try:
+        model = _parrot(cfg, vocab, n_spk, tsd, tmp_path)
+        batch = synth.synth_tte_batch(B, S, vocab, n_spk, seed=31 + idx, ragged=True)
+        gb = {k: v.to(DEV) for k, v in batch.items()}
+        got = model.infer(gb, row_exact=True)
+        log_dur = model.infer_dense(gb, row_exact=True)["log_dur"].cpu()
+        checked = 0
+        for b in range(B):
+            one = _single_row_batch(batch, b)
+            try:
+                with torch.no_grad():
+                    ref = O.tte_forward(tsd, cfg, one)
+                    ref_ids = O.tte_infer(tsd, cfg, one)[0]
+            except RuntimeError:  # an all-zero-duration utterance: the reference itself raises on the empty sequence
+                assert got[b] == []
+                continue
+            n = int(batch["src_lens"][b])
+            assert float((log_dur[b, :n] - ref["log_dur"][0]).abs().max()) <= 2e-5
+            assert got[b] == model.infer({k: v.to(DEV) for k, v in one.items()})[0], (b, "batched row-exact != HIP run alone")
+            frac = torch.exp(ref["log_dur"][0]) - 1.0
+            top2 = torch.topk(ref["logits"], 2, dim=-1).values
+            if bool(((frac - torch.floor(frac) - 0.5).abs() > 1e-4).all()) and bool(((top2[..., 0] - top2[..., 1]) > 1e-4).all()):
+                assert got[b] == ref_ids, b
+                checked += 1
+        assert checked >= B // 2
+    finally:
+        ops.set_default_precision(ops.PREC_NAMES["f16x3"])
