@@ -63,7 +63,23 @@ def param_fingerprint(module) -> tuple:
     """Identity + version of every parameter / buffer of ``module``: changes whenever a tensor is replaced, moved or
     written in place (``load_state_dict`` through ANY parent module copies in place and bumps ``_version``).  The HIP
     handle caches packed copies of the weights, so the shims compare this before every forward and rebuild on mismatch."""
-    return tuple((id(t), t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+    # (a direct walk over the modules' own dicts: `module.parameters()` -- a generator over named_modules with name strings and a
+    #  memo set -- cost 390-460 us per call on the full-size generator, on the host's critical path between the TTE's last launch and
+    #  the vocoder's first at small batches; this is 130 us and sees the same tensors)
+    out = []
+    stack = [module]
+    while stack:
+        m = stack.pop()
+        for t in m._parameters.values():
+            if t is not None:
+                out.append((id(t), t.data_ptr(), t._version))
+        for t in m._buffers.values():
+            if t is not None:
+                out.append((id(t), t.data_ptr(), t._version))
+        for c in m._modules.values():
+            if c is not None:
+                stack.append(c)
+    return tuple(out)
 
 
 def selftest() -> None:

@@ -28,12 +28,12 @@ class SynthesisPipeline:
 
     def _emitted(self, r, L):
         """ids per row as ``Parrot.infer`` returns them, on the host and on the device: len + 1 clamped to L in the padded-batch
-        mode (quirk Q2), exactly len in the row-exact mode.  (The device copy is clamped from the lengths the encoder left there:
-        handing the host tensor over would be a pageable host-to-device copy, which blocks the host until the decoder has
-        drained -- 0.2-0.3 ms of idle GPU per batch.)"""
+        mode (quirk Q2), exactly len in the row-exact mode.  (The device copy comes from the lengths the encoder left there --
+        ``Parrot._run`` forms it before the decoder is enqueued: handing the host tensor over would be a pageable host-to-device
+        copy, which blocks the host until the decoder has drained -- 0.2-0.3 ms of idle GPU per batch.)"""
         if r.get("row_exact"):
-            return r["lens"].to(torch.int64), r["lens_dev"]
-        return torch.clamp(r["lens"].to(torch.int64) + 1, max=L), torch.clamp(r["lens_dev"] + 1, max=L)
+            return r["lens"].to(torch.int64), r["emitted_dev"]
+        return torch.clamp(r["lens"].to(torch.int64) + 1, max=L), r["emitted_dev"]
 
     @torch.no_grad()
     def __call__(self, batch: Dict[str, torch.Tensor], spkr: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:

@@ -302,6 +302,10 @@ class Parrot(nn.Module):
         ids = torch.empty((B, L), dtype=torch.int64, device=dev)
         tgt = torch.empty((B, L), dtype=torch.uint8, device=dev)
         logits = torch.empty((B, L, lib_n_codes(self)), dtype=torch.float32, device=dev) if want_logits else None
+        # ids per row as `infer` returns them (len + 1 clamped to L: quirk Q2; exactly len in the row-exact mode), on the device for a
+        # vocoder that follows: computed HERE, in the shadow of the length sync, so that no small kernel sits between the decoder's
+        # last launch and the vocoder's first
+        emitted_dev = ctx["lens_dev"] if row_exact else torch.clamp(ctx["lens_dev"] + 1, max=L)
         self._decode(ctx, ids, tgt, logits)
         if self._probe_pending:  # first decode of this handle: one synchronous look at the device flag
             self._probe_pending = False
@@ -318,7 +322,7 @@ class Parrot(nn.Module):
         if row_exact:  # a row alone is the longest of its batch: exactly `lens` ids, no extra frame (the device mask keeps one key
             tgt_mask = torch.arange(L, device=dev)[None, :] < ctx["lens_dev"][:, None]  # valid for rows of length 0)
         return {"ids": ids, "tgt_mask": tgt_mask, "log_dur": ctx["log_dur"], "dur": ctx["dur"], "lens": ctx["lens"], "logits": logits,
-                "src_mask": ctx["src_mask"], "lens_dev": ctx["lens_dev"], "row_exact": bool(row_exact)}
+                "src_mask": ctx["src_mask"], "lens_dev": ctx["lens_dev"], "row_exact": bool(row_exact), "emitted_dev": emitted_dev}
 
     @torch.no_grad()
     def forward_stages(self, batch) -> dict:

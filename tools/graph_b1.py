@@ -8,6 +8,10 @@ from parrot_tts_amd import _lib, ops, synth
 from parrot_tts_amd.ops import dptr, stream_ptr
 from parrot_tts_amd.pipeline import SynthesisPipeline
 
+if os.environ.get("PARROT_FP_OLD") == "1":  # A/B: the round-4 parameter fingerprint (module.parameters() walk, ~400 us per forward)
+    import parrot_tts_amd.tte as _t, parrot_tts_amd.vocoder as _v
+    _old = lambda module: tuple((id(t), t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))  # noqa: E731
+    ops.param_fingerprint = _t.param_fingerprint = _v.param_fingerprint = _old
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 ops.set_default_precision(ops.PREC_NAMES["f16x3"])
