@@ -693,26 +693,46 @@ struct parrot_voc {
     hipEvent_t ev_lane_fork = nullptr, ev_lane_join[MAX_LANES] = {};
     float* dbg_absmax = nullptr;       // parrot_voc_debug_absmax: (n_stages + 2) device floats, max |conv input| per group (caller-owned)
     // HIP-graph replay of small forwards (PARROT_VOC_GRAPH, default on; B x U <= 8192 units): a forward is ~130 dependent launches
-    // of 7-40 us on up to three streams -- at one utterance the fork / join events and the launch gaps are a fifth of it.  A call
-    // whose every pointer and size equals an earlier call's is captured once (at its second sighting: the first warms lazy state)
-    // and replayed afterwards: the same kernels with the same arguments, the branch streams as graph edges.
+    // of 7-40 us on up to three streams -- at one utterance the fork / join events and the launch gaps are a fifth of it.  A SHAPE
+    // (B, U, with / without speaker ids and row lengths) that keeps recurring is captured once (GRAPH_AFTER below; the first calls also warm lazy
+    // state), on a stream of the handle and into staging buffers of the handle (ids, lengths, waveform, workspace: one allocation per
+    // cached shape, made at capture time -- never per call): PyTorch's allocator hands out different addresses from call to call, and
+    // a graph bakes its addresses in.  A replay copies the caller's ids / lengths in (a few KB), launches the graph and copies the
+    // waveform out: the same kernels with the same arguments in the same order, the MRF branch streams as graph edges.
     struct Graph {
-        const void *code, *spkr, *feats, *lens, *wav, *ws;
-        int code_stride, n_feat, B, U;
-        size_t ws_bytes;
+        int B = 0, U = 0;
+        bool has_spkr = false, has_lens = false;
+        char* mem = nullptr;  // one allocation: code | spkr | lens | wav | ws
+        int64_t *code = nullptr, *spkr = nullptr;
+        int32_t* lens = nullptr;
+        float* wav = nullptr;
+        void* ws = nullptr;
+        size_t ws_bytes = 0, wav_bytes = 0, mem_bytes = 0;
         hipGraphExec_t exec = nullptr;
+        hipEvent_t done = nullptr;     // recorded behind the last replay's copy-out: a replay on ANOTHER stream waits for it first
+        hipStream_t last = nullptr;
+        bool launched = false, dead = false;
         int seen = 0;
         unsigned long stamp = 0;
+        void release() {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (done) (void)hipEventDestroy(done);
+            if (mem) (void)hipFree(mem);
+            exec = nullptr; done = nullptr; mem = nullptr;
+        }
     };
-    static constexpr int MAX_GRAPHS = 8;
+    // A shape is captured at its GRAPH_AFTER-th sighting (capture + instantiate + the staging allocation cost milliseconds: a
+    // driver that feeds ever-changing lengths, one utterance per call, must not pay them -- it never does: its shapes do not recur
+    // often enough within the MAX_SHAPES most recent ones); at most MAX_GRAPHS shapes hold a graph, least recently used first out
+    static constexpr int MAX_GRAPHS = 8, MAX_SHAPES = 64, GRAPH_AFTER = 4;
+    static constexpr size_t MAX_GRAPH_BYTES = (size_t)4 << 30;  // staging memory of all cached shapes together
     std::vector<Graph> graphs;
     std::mutex graph_mu;
     unsigned long graph_clock = 0;
     bool graph_on = true;
     hipStream_t cap_stream = nullptr;
     ~parrot_voc() {
-        for (Graph& g : graphs)
-            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        for (Graph& g : graphs) g.release();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (StreamSet& q : ss) {
             for (hipStream_t st : q.side)
@@ -1185,63 +1205,113 @@ static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_st
                                void* ws, size_t ws_bytes, void* stream) {
     static const bool want = [] { const char* e = getenv("PARROT_VOC_GRAPH"); return !e || atoi(e) != 0; }();
     hipStream_t s = (hipStream_t)stream;
+    auto direct = [&]() { return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream); };
     const bool small = v && B > 0 && U > 0 && (long)B * U <= 8192;
-    if (!want || !small || !v->graph_on || stage_out || v->dbg_absmax || g_prof_on || !code || !wav_out || !ws)
-        return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+    if (!want || !small || !v->graph_on || stage_out || v->dbg_absmax || g_prof_on || !code || !wav_out || !ws || n_feat != 0 || feats ||
+        (v->cfg.multispkr && !spkr) || v->cfg.model_in_dim != v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1))
+        return direct();  // (argument errors are reported by the direct path)
     {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone)  // the caller is capturing: stay inside ITS graph
-            return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return direct();  // the caller is capturing: stay inside ITS graph
     }
+    // the caller's workspace must be what a direct run needs (a replay does not touch it, but the contract is the same call)
+    if (ws_bytes < voc_ws_bytes(v, B, U, voc_streams(v, B, U))) return direct();
+    const bool has_spkr = v->cfg.multispkr && spkr != nullptr, has_lens = unit_lens != nullptr;
     std::unique_lock<std::mutex> lk(v->graph_mu);
     parrot_voc::Graph* g = nullptr;
     for (parrot_voc::Graph& q : v->graphs)
-        if (q.code == code && q.spkr == spkr && q.feats == feats && q.lens == unit_lens && q.wav == wav_out && q.ws == ws &&
-            q.code_stride == code_stride && q.n_feat == n_feat && q.B == B && q.U == U && q.ws_bytes == ws_bytes) {
+        if (q.B == B && q.U == U && q.has_spkr == has_spkr && q.has_lens == has_lens) {
             g = &q;
             break;
         }
-    if (!g) {  // first sighting: remember it (evicting the least recently used entry), run directly
-        if ((int)v->graphs.size() >= parrot_voc::MAX_GRAPHS) {
+    auto drop = [&](size_t i) {  // (a graph may still be running: its buffers are freed only after the device has drained what uses them)
+        if (v->graphs[i].launched && v->graphs[i].done) (void)hipEventSynchronize(v->graphs[i].done);
+        v->graphs[i].release();
+    };
+    if (!g) {  // first sighting: count the shape (the least recently seen shape makes room), run directly
+        if ((int)v->graphs.size() >= parrot_voc::MAX_SHAPES) {
             size_t old = 0;
             for (size_t i = 1; i < v->graphs.size(); ++i)
                 if (v->graphs[i].stamp < v->graphs[old].stamp) old = i;
-            if (v->graphs[old].exec) (void)hipGraphExecDestroy(v->graphs[old].exec);
+            drop(old);
             v->graphs.erase(v->graphs.begin() + old);
         }
         parrot_voc::Graph q{};
-        q.code = code; q.spkr = spkr; q.feats = feats; q.lens = unit_lens; q.wav = wav_out; q.ws = ws;
-        q.code_stride = code_stride; q.n_feat = n_feat; q.B = B; q.U = U; q.ws_bytes = ws_bytes;
+        q.B = B; q.U = U; q.has_spkr = has_spkr; q.has_lens = has_lens;
         q.seen = 1;
         q.stamp = ++v->graph_clock;
         v->graphs.push_back(q);
         lk.unlock();
-        return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+        return direct();
     }
     g->stamp = ++v->graph_clock;
-    if (!g->exec) {  // second sighting: capture -- on the handle's own stream (the caller's may be the legacy default stream, which
-        hipGraph_t graph = nullptr;  // cannot capture); nothing runs during the capture, the instantiated graph is launched on `s` below
-        if (!v->cap_stream && hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking) != hipSuccess) v->cap_stream = nullptr;
-        if (!v->cap_stream || hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
-            (void)hipGetLastError();
-            v->graph_on = false;
-            lk.unlock();
-            return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
-        }
-        const int rc = voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, nullptr, ws, ws_bytes, (void*)v->cap_stream);
-        const hipError_t e_end = hipStreamEndCapture(v->cap_stream, &graph);
-        hipGraphExec_t exec = nullptr;
-        if (rc != PARROT_OK || e_end != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            if (graph) (void)hipGraphDestroy(graph);
-            v->graph_on = false;  // this handle goes direct from now on (the argument errors of rc are reported by the direct run)
-            lk.unlock();
-            return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
-        }
-        (void)hipGraphDestroy(graph);
-        g->exec = exec;
+    if (g->dead || (!g->exec && ++g->seen < parrot_voc::GRAPH_AFTER)) {
+        lk.unlock();
+        return direct();
     }
+    if (!g->exec) {  // this shape keeps coming: it takes a graph slot (the least recently used graph gives its slot up)
+        int n_graphs = 0;
+        size_t lru = v->graphs.size();
+        for (size_t i = 0; i < v->graphs.size(); ++i)
+            if (v->graphs[i].exec) {
+                ++n_graphs;
+                if (lru == v->graphs.size() || v->graphs[i].stamp < v->graphs[lru].stamp) lru = i;
+            }
+        if (n_graphs >= parrot_voc::MAX_GRAPHS) {
+            drop(lru);
+            v->graphs[lru].mem_bytes = 0;
+            v->graphs[lru].seen = 0;
+            v->graphs[lru].launched = false;
+        }
+    }
+    if (!g->exec) {  // staging buffers + capture on the handle's own stream (nothing runs during the capture)
+        const size_t n_code = (size_t)B * U * sizeof(int64_t), n_spkr = has_spkr ? (size_t)B * sizeof(int64_t) : 0,
+                     n_lens = has_lens ? (size_t)B * sizeof(int32_t) : 0;
+        g->wav_bytes = (size_t)B * (size_t)voc_out_len(v, U) * sizeof(float);
+        g->ws_bytes = voc_ws_bytes(v, B, U, voc_streams(v, B, U));
+        size_t off = 0;
+        auto take = [&](size_t n) { const size_t o = off; off = align_up(off + n, 256); return o; };
+        const size_t o_code = take(n_code), o_spkr = take(n_spkr), o_lens = take(n_lens), o_wav = take(g->wav_bytes), o_ws = take(g->ws_bytes);
+        size_t in_use = 0;
+        for (const parrot_voc::Graph& q : v->graphs) in_use += q.mem_bytes;
+        bool ok = in_use + off <= parrot_voc::MAX_GRAPH_BYTES && hipMalloc((void**)&g->mem, off) == hipSuccess;
+        if (ok) {
+            g->mem_bytes = off;
+            g->code = reinterpret_cast<int64_t*>(g->mem + o_code);
+            g->spkr = has_spkr ? reinterpret_cast<int64_t*>(g->mem + o_spkr) : nullptr;
+            g->lens = has_lens ? reinterpret_cast<int32_t*>(g->mem + o_lens) : nullptr;
+            g->wav = reinterpret_cast<float*>(g->mem + o_wav);
+            g->ws = g->mem + o_ws;
+            ok = hipEventCreateWithFlags(&g->done, hipEventDisableTiming) == hipSuccess;
+        }
+        if (ok && !v->cap_stream) ok = hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking) == hipSuccess;
+        hipGraph_t graph = nullptr;
+        if (ok) ok = hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            const int rc = voc_forward_impl(v, g->code, U, g->spkr, nullptr, 0, g->lens, B, U, g->wav, nullptr, g->ws, g->ws_bytes, (void*)v->cap_stream);
+            const hipError_t e_end = hipStreamEndCapture(v->cap_stream, &graph);
+            ok = rc == PARROT_OK && e_end == hipSuccess && graph && hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {  // this shape goes direct from now on
+            (void)hipGetLastError();
+            g->release();
+            g->mem_bytes = 0;
+            g->dead = true;
+            lk.unlock();
+            return direct();
+        }
+    }
+    if (g->launched && g->last != s) HIP_TRY(hipStreamWaitEvent(s, g->done, 0));  // the staging buffers are still the previous replay's
+    HIP_TRY(hipMemcpy2DAsync(g->code, (size_t)U * sizeof(int64_t), code, (size_t)code_stride * sizeof(int64_t), (size_t)U * sizeof(int64_t), B,
+                             hipMemcpyDeviceToDevice, s));
+    if (g->spkr) HIP_TRY(hipMemcpyAsync(g->spkr, spkr, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    if (g->lens) HIP_TRY(hipMemcpyAsync(g->lens, unit_lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGraphLaunch(g->exec, s));
+    HIP_TRY(hipMemcpyAsync(wav_out, g->wav, g->wav_bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipEventRecord(g->done, s));
+    g->last = s;
+    g->launched = true;
     return PARROT_OK;
 }
 

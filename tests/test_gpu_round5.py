@@ -219,30 +219,34 @@ def test_single_chunk_calls_of_the_chunked_forward_equal_the_whole_forward():
 
 
 def test_graph_replay_of_small_forwards_is_bit_identical_to_direct_launches():
-    """small forwards (B x U <= 8192 units) whose pointers and sizes recur are captured into a HIP graph at their
-    second sighting and replayed afterwards (the MRF branch streams become graph edges).  Replays must equal direct launches bit
-    for bit, for new CONTENTS in the same buffers, dense and ragged."""
+    """small forwards (B x U <= 8192 units) of a SHAPE that recurs are captured into a HIP graph at the fourth
+    sighting -- on staging buffers of the handle, because PyTorch hands out new addresses from call to call -- and replayed
+    afterwards (the MRF branch streams become graph edges).  Replays must equal direct launches bit for bit: fresh tensors every
+    call, new contents, dense and ragged; a forward that asks for stage activations takes the direct path and is the reference."""
     h = synth.default_voc_config()
     g = _gen(h, synth.synth_voc_state_dict(h, seed=1234, scale=1.0))
-    B, U = 2, 48
-    code = torch.zeros((B, U), dtype=torch.int64, device=DEV)
-    spkr = torch.zeros((B, 1), dtype=torch.int64, device=DEV)
-    lens = torch.full((B,), U, dtype=torch.int32, device=DEV)
-    out = torch.empty((B, 1, g.out_samples(U)), dtype=torch.float32, device=DEV)
     hop = g.upsample_factor
-    for it in range(5):  # 1: direct, 2: capture + launch, 3-5: replay
-        b = synth.synth_voc_batch(B, U, h, seed=100 + it)
-        code.copy_(b["code"].to(DEV))
-        spkr.copy_(b["spkr"].to(DEV))
-        lens.copy_(torch.tensor([U, U - 7 - it], dtype=torch.int32))
-        y = g(code=code, spkr=spkr, unit_lens=lens, out=out)
-        assert y.data_ptr() == out.data_ptr()
-        ref = g(code=code.clone(), spkr=spkr.clone(), unit_lens=lens.clone())  # fresh pointers: a first sighting, i.e. direct launches
-        torch.cuda.synchronize()
-        for r in range(B):
-            n = int(lens[r]) * hop
-            assert torch.equal(y[r, :, :n], ref[r, :, :n]), (it, r)
+    for B, U in ((2, 48), (1, 256)):
+        for it in range(8):  # 1-3: direct, 4: capture + launch, 5-8: replay
+            b = synth.synth_voc_batch(B, U, h, seed=100 + it)
+            code, spkr = b["code"].to(DEV), b["spkr"].to(DEV)  # new device tensors (new addresses) every iteration
+            lens = torch.tensor([U] + [U - 7 - it] * (B - 1), dtype=torch.int32, device=DEV)
+            y = g(code=code, spkr=spkr, unit_lens=lens)
+            ref = g(code=code, spkr=spkr, unit_lens=lens, stages={})  # stage capture: always direct launches
+            torch.cuda.synchronize()
+            for r in range(B):
+                n = int(lens[r]) * hop
+                assert torch.equal(y[r, :, :n], ref[r, :, :n]), (B, U, it, r)
+        dense = g(code=code, spkr=spkr)  # another shape class (no row lengths): its own graph
+        assert torch.equal(dense, g(code=code, spkr=spkr, stages={}))
     g.check_inputs()
+    # a bad unit id is still flagged through the replayed graph
+    bad = code.clone()
+    bad[0, 3] = 10 ** 6
+    for _ in range(6):
+        g(code=bad, spkr=spkr)
+    with pytest.raises(IndexError):
+        g.check_inputs()
 
 
 def _snr_db(y, ref):
