@@ -34,6 +34,22 @@ constexpr int RBS_MAX_CONVS = 8;    // convs of one ResBlock (pairs x 2)
 constexpr int RBS_MAX_BRANCH = 4;   // MRF branches of a stage (PARROT_MAX_KERNELS)
 constexpr int RBS_MAX_ALL = RBS_MAX_CONVS * RBS_MAX_BRANCH;
 
+// Phase trace (experiment builds only, tools/build_exp.sh trace -DRBS_TRACE): one workgroup of the 32-channel kernels stamps the
+// shader clock (s_memtime) at every phase boundary -- [wave][stamp] in a device array read back by parrot_debug_rbs_trace.
+#ifdef RBS_TRACE
+constexpr int RBS_TRACE_STAMPS = 128;
+__device__ unsigned long long g_rbs_trace[8 * RBS_TRACE_STAMPS];
+#define RBS_STAMP()                                                                                                   \
+    do {                                                                                                              \
+        if (trace_on && trace_n < RBS_TRACE_STAMPS) {                                                                 \
+            const unsigned long long tt = __builtin_amdgcn_s_memtime();                                               \
+            if (lane == 0) g_rbs_trace[wave * RBS_TRACE_STAMPS + trace_n] = tt;                                       \
+        }                                                                                                             \
+        ++trace_n;                                                                                                    \
+    } while (0)
+#else
+#define RBS_STAMP() do {} while (0)
+#endif
 // 1 (default): a wave converts the columns no other wave reads BEFORE the barrier that ends a conv (see write_p); 0: round-4 order
 #ifndef RBS_EARLY_INNER
 #define RBS_EARLY_INNER 1
@@ -106,6 +122,11 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
     const int t_base = tile * p.TT - p.H;  // sequence position of window column 0
     const int Tlim = p.row_len ? min(p.T, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.T;
     const bool edge = __builtin_amdgcn_readfirstlane((t_base < 0 || t_base + W > Tlim) ? 1 : 0);  // window not fully inside the row
+#ifdef RBS_TRACE
+    const bool trace_on = NCH == 2 && blockIdx.x == gridDim.x / 2;  // one mid-launch workgroup of the 32-channel kernels
+    int trace_n = 0;
+    RBS_STAMP();  // 0: start
+#endif
 
     int col[NTW];   // this lane's window column per tile
     bool tok[NTW];  // ... inside the sequence
@@ -205,8 +226,11 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
         load_a_piece(A[1], pc, gbase + K);  // (tap 0, chunk 1)
     }
 
+    RBS_STAMP();  // 1: window loaded (issued), weights prefetched
     write_p(R, SCH::XS);  // (out-of-sequence columns of R are 0 from the range-checked loads)
+    RBS_STAMP();  // 2: first conversion done
     __syncthreads();
+    RBS_STAMP();  // 3: barrier
 
     int center = (K - 1) / 2;
     auto load_b = [&](s16x8 (&bb)[NTW][NPC], int ch, int shift) __attribute__((always_inline)) {
@@ -285,9 +309,13 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
             load_a_piece(A[0], pc, gbase);
             load_a_piece(A[1], pc, gbase + K);
         }
+        RBS_STAMP();  // branch switch: loads issued
         __syncthreads();  // every wave is done with the previous branch's last conv (reads of P)
+        RBS_STAMP();
         write_p(R, SCH::XS);
+        RBS_STAMP();
         __syncthreads();
+        RBS_STAMP();
     }
     // R is carried in SCALED form between pairs: after a pair's second conv the accumulator IS the new residual times rs = XS * wsc
     // of that conv, and it stays in its registers -- the next second conv starts from fma(R, s2 / rs, b2 * s2) in place, the operand
@@ -304,11 +332,17 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = (SCH::XS != 1.f) ? bv[r] * s1 : bv[r];
+        RBS_STAMP();  // A: accumulators initialised
         conv(acc, p.dil[m]);
+        RBS_STAMP();  // B: conv done
         if (early) write_p(acc, 1.f / p.wsc[m], 1);
+        RBS_STAMP();  // C: inner tile converted
         __syncthreads();  // every wave is done reading P
+        RBS_STAMP();  // D: barrier
         write_p(acc, 1.f / p.wsc[m], early ? 2 : 0);  // P = split(lrelu(h)), masked: acc / s1 * XS
+        RBS_STAMP();  // E: outer tiles converted
         __syncthreads();
+        RBS_STAMP();  // F: barrier
         // R = conv_1(P) + b2 + R, accumulated IN R's registers
         bias_rows(p.bias[m + 1], bv);
         if constexpr (SCH::XS != 1.f) {
@@ -327,15 +361,21 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
         }
         // (the residual rides in the accumulator: keeping R live across this conv costs 48 VGPRs, i.e. the third workgroup per
         //  CU or spills -- measured 4.8 -> 8.1 ms per step; in the vocoder |x| ~ |conv sum|, so folding costs no accuracy)
+        RBS_STAMP();  // A
         conv(R, p.dil[m + 1]);
+        RBS_STAMP();  // B
         rs = (SCH::XS != 1.f) ? s2 : 1.f;
         // (columns outside the sequence now hold garbage in R: they never feed a valid column -- write_p zeroes their operand slots --
         //  and the final store drops them or leaves them in the row's unspecified tail)
         if (mm + 2 < p.n_conv) {
             if (early) write_p(R, SCH::XS / rs, 1);
+            RBS_STAMP();  // C
             __syncthreads();
+            RBS_STAMP();  // D
             write_p(R, SCH::XS / rs, early ? 2 : 0);
+            RBS_STAMP();  // E
             __syncthreads();
+            RBS_STAMP();  // F
         }
     }
     if constexpr (SCH::XS != 1.f) {  // back to the plain residual for the branch sum / the store
@@ -353,6 +393,7 @@ __global__ __launch_bounds__((NCH / 2) * (WN ? WN : rbs_default_wn(NCH)) * 64,
     }
     }  // branches
 
+    RBS_STAMP();  // compute done
     // ---- write the central TT columns (registers -> global, 128-byte runs per row) ---------------------------------
     // buffer-addressed like the layer kernels' RowTile (conv_mfma.h): ONE lane-dependent offset per column tile (0x80000000 for a
     // column outside the window's own output range: loads return 0, stores are dropped), scalar row offsets -- the 64-bit pointer
