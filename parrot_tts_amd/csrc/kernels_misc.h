@@ -217,14 +217,17 @@ static __global__ __launch_bounds__(256) void softmax_mask_kernel(float* __restr
 static __global__ __launch_bounds__(256) void duration_kernel(const float* __restrict__ ld_raw, const uint8_t* __restrict__ src_valid,
                                                        float* __restrict__ log_dur, int64_t* __restrict__ dur,
                                                        int32_t* __restrict__ cum /* (B,S) inclusive */, int32_t* __restrict__ out_len,
-                                                       int S) {
+                                                       int S, const int32_t* __restrict__ src_len = nullptr) {
     __shared__ int32_t part[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int per = (S + 255) / 256;
     const int s_begin = tid * per, s_end = min(S, s_begin + per);
     int32_t local = 0;
     for (int s = s_begin; s < s_end; ++s) {
-        float v = src_valid[(size_t)b * S + s] ? ld_raw[(size_t)b * S + s] : 0.0f;
+        // (row-exact: the row's own token count decides, not the key mask -- a row of NO tokens keeps key 0 attendable so that its
+        //  softmax is defined, and must still expand to nothing)
+        const bool real = src_len ? s < src_len[b] : src_valid[(size_t)b * S + s] != 0;
+        float v = real ? ld_raw[(size_t)b * S + s] : 0.0f;
         log_dur[(size_t)b * S + s] = v;
         float d = rintf(expf(v) - 1.0f);
         d = d > 0.f ? d : 0.f;
@@ -310,7 +313,9 @@ static __global__ __launch_bounds__(256) void length_regulate_kernel(const float
     // padded batch: pe[L] of the batch-max length and the `<=` mask (one extra frame per shorter row, quirk Q2); row-exact: what the
     // row's own B = 1 run sees -- pe[len] and exactly len frames (get_mask_from_lengths(len, max_len = len) is all True)
     const float* __restrict__ pe_row = pe + (size_t)(row_exact ? min(len, L) : L) * (pe_stride < 0 ? D : pe_stride);  // (pe_stride 0: one row for every length)
-    if (wave == 0) tgt_mask[(size_t)b * L + t] = (row_exact ? t < len : t <= len) ? 1 : 0;
+    // (row-exact rows of length 0 keep key 0 valid: a softmax over no keys at all is 0 / 0, and its NaN would raise the batch's
+    //  non-finite flag for a row that emits nothing -- the host recomputes the returned mask from the lengths)
+    if (wave == 0) tgt_mask[(size_t)b * L + t] = (row_exact ? t < max(len, 1) : t <= len) ? 1 : 0;
     int src = -1;
     if (t < len) {
         const int32_t* cb = cum + (size_t)b * S;
@@ -383,9 +388,9 @@ static __global__ __launch_bounds__(64 * ARGMAX_WAVES) void argmax_cf_kernel(con
         ids[(size_t)b * L + t] = mi;
         if (err && nf) atomicExch(err, 5);  // NaN / inf logits (an activation left the fp16 split range)
         if (gstat) {
-            const float margin = m - s2;  // >= 0 (NaN when non-finite: flagged above, fails the comparisons below)
+            const float margin = m - s2;  // >= 0, or NaN when the column holds non-finite logits (flagged above)
             if (margin >= 0.f) atomicMin(gstat + 2, __float_as_int(margin));
-            if (margin < guard) {
+            if (!(margin >= guard)) {  // (a NaN margin is guarded too: a non-finite logit never silently skips the re-evaluation)
                 const int slot = atomicAdd(gstat, 1);
                 if (slot < TIE_GUARD_MAX) { glist[2 * slot] = row0 + b; glist[2 * slot + 1] = t; }  // (batch row; b is the row inside this group)
             }

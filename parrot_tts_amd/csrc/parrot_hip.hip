@@ -69,6 +69,35 @@ struct Arena {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Poison mode (tests only): PARROT_POISON_WS = nan | inf | 7f fills every caller-provided workspace / state / output buffer -- and
+// the graph cache's staging buffers -- with that bit pattern at the top of each compute entry point, on the caller's stream.  A
+// kernel that reads a byte nobody wrote then fails deterministically (NaN / 0 x inf / 3.4e38 in the result) instead of depending
+// on what the allocator happened to leave behind.  Unset: no cost, no launches.
+// ---------------------------------------------------------------------------------------------
+static uint32_t poison_word() {
+    static const uint32_t w = [] {
+        const char* e = getenv("PARROT_POISON_WS");
+        if (!e || !*e || !strcmp(e, "0")) return 0u;
+        if (!strcmp(e, "inf")) return 0x7f800000u;
+        if (!strcmp(e, "7f")) return 0x7f7f7f7fu;
+        return 0x7fc00000u;  // "nan", "1", anything else
+    }();
+    return w;
+}
+static int poison(void* p, size_t bytes, hipStream_t s) {
+    const uint32_t w = poison_word();
+    if (!w || !p || bytes == 0) return PARROT_OK;
+    if ((uintptr_t)p & 3) {  // (an unaligned view: bytes)
+        HIP_TRY(hipMemsetAsync(p, 0x7f, bytes, s));
+        return PARROT_OK;
+    }
+    const size_t words = bytes / 4;
+    if (words) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p, (int)w, words, s));
+    if (bytes & 3) HIP_TRY(hipMemsetAsync((char*)p + 4 * words, 0x7f, bytes & 3, s));
+    return PARROT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // optional per-launch timing of the conv kernel (HIP events on the launch stream), aggregated per
 // tile configuration: feeds bench.py's roofline object.  Off by default.
 // ---------------------------------------------------------------------------------------------
@@ -629,6 +658,8 @@ extern "C" int parrot_conv_run(parrot_conv_t* c, const float* x, const float* re
                                int32_t epilogue, float div, void* stream) {
     if (!c || !x || !y) return fail(PARROT_E_INVALID, "conv_run: null argument");
     if (epilogue < 0 || epilogue > 2) return fail(PARROT_E_INVALID, "conv_run: bad epilogue");
+    if (epilogue == EPI_STORE && y != x && y != res && c->out_len(T_in) > 0)
+        TRY(poison(y, (size_t)B * c->Cout * c->out_len(T_in) * sizeof(float), (hipStream_t)stream));
     return conv_launch(c, x, res, y, B, T_in, epilogue, div, 0, 0, 0, (hipStream_t)stream);
 }
 
@@ -725,11 +756,10 @@ struct parrot_voc {
     // driver that feeds ever-changing lengths, one utterance per call, must not pay them -- it never does: its shapes do not recur
     // often enough within the MAX_SHAPES most recent ones); at most MAX_GRAPHS shapes hold a graph, least recently used first out
     static constexpr int MAX_GRAPHS = 8, MAX_SHAPES = 64, GRAPH_AFTER = 4;
-    static constexpr size_t MAX_GRAPH_BYTES = (size_t)4 << 30;  // staging memory of all cached shapes together
+    // (staging memory of all cached shapes of a handle together: PARROT_VOC_GRAPH_MB, default 1024 -- see voc_forward_graphed)
     std::vector<Graph> graphs;
     std::mutex graph_mu;
     unsigned long graph_clock = 0;
-    bool graph_on = true;
     hipStream_t cap_stream = nullptr;
     ~parrot_voc() {
         for (Graph& g : graphs) g.release();
@@ -1205,9 +1235,15 @@ static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_st
                                void* ws, size_t ws_bytes, void* stream) {
     static const bool want = [] { const char* e = getenv("PARROT_VOC_GRAPH"); return !e || atoi(e) != 0; }();
     hipStream_t s = (hipStream_t)stream;
-    auto direct = [&]() { return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream); };
+    auto direct = [&]() {
+        if (poison_word() && v && B > 0 && U > 0) {
+            TRY(poison(ws, ws_bytes, s));
+            if (wav_out) TRY(poison(wav_out, (size_t)B * (size_t)voc_out_len(v, U) * sizeof(float), s));
+        }
+        return voc_forward_impl(v, code, code_stride, spkr, feats, n_feat, unit_lens, B, U, wav_out, stage_out, ws, ws_bytes, stream);
+    };
     const bool small = v && B > 0 && U > 0 && (long)B * U <= 8192;
-    if (!want || !small || !v->graph_on || stage_out || v->dbg_absmax || g_prof_on || !code || !wav_out || !ws || n_feat != 0 || feats ||
+    if (!want || !small || stage_out || v->dbg_absmax || g_prof_on || !code || !wav_out || !ws || n_feat != 0 || feats ||
         (v->cfg.multispkr && !spkr) || v->cfg.model_in_dim != v->cfg.embedding_dim * (v->cfg.multispkr ? 2 : 1))
         return direct();  // (argument errors are reported by the direct path)
     {
@@ -1249,22 +1285,7 @@ static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_st
         lk.unlock();
         return direct();
     }
-    if (!g->exec) {  // this shape keeps coming: it takes a graph slot (the least recently used graph gives its slot up)
-        int n_graphs = 0;
-        size_t lru = v->graphs.size();
-        for (size_t i = 0; i < v->graphs.size(); ++i)
-            if (v->graphs[i].exec) {
-                ++n_graphs;
-                if (lru == v->graphs.size() || v->graphs[i].stamp < v->graphs[lru].stamp) lru = i;
-            }
-        if (n_graphs >= parrot_voc::MAX_GRAPHS) {
-            drop(lru);
-            v->graphs[lru].mem_bytes = 0;
-            v->graphs[lru].seen = 0;
-            v->graphs[lru].launched = false;
-        }
-    }
-    if (!g->exec) {  // staging buffers + capture on the handle's own stream (nothing runs during the capture)
+    if (!g->exec) {  // this shape keeps coming: staging buffers + capture on the handle's own stream (nothing runs during the capture)
         const size_t n_code = (size_t)B * U * sizeof(int64_t), n_spkr = has_spkr ? (size_t)B * sizeof(int64_t) : 0,
                      n_lens = has_lens ? (size_t)B * sizeof(int32_t) : 0;
         g->wav_bytes = (size_t)B * (size_t)voc_out_len(v, U) * sizeof(float);
@@ -1272,9 +1293,33 @@ static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_st
         size_t off = 0;
         auto take = [&](size_t n) { const size_t o = off; off = align_up(off + n, 256); return o; };
         const size_t o_code = take(n_code), o_spkr = take(n_spkr), o_lens = take(n_lens), o_wav = take(g->wav_bytes), o_ws = take(g->ws_bytes);
+        // it takes a graph slot and `off` bytes of staging memory: least recently used graphs give theirs up until both fit
+        // (PARROT_VOC_GRAPH_MB caps the staging memory of one handle, default 1024 -- it is hipMalloc'ed, outside torch's allocator)
+        static const size_t cap = [] { const char* e = getenv("PARROT_VOC_GRAPH_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 1024) << 20; }();
+        for (;;) {
+            int n_graphs = 0;
+            size_t in_use = 0, lru = v->graphs.size();
+            for (size_t i = 0; i < v->graphs.size(); ++i) {
+                in_use += v->graphs[i].mem_bytes;
+                if (v->graphs[i].exec) {
+                    ++n_graphs;
+                    if (lru == v->graphs.size() || v->graphs[i].stamp < v->graphs[lru].stamp) lru = i;
+                }
+            }
+            if ((n_graphs < parrot_voc::MAX_GRAPHS && in_use + off <= cap) || lru == v->graphs.size()) break;
+            drop(lru);
+            v->graphs[lru].mem_bytes = 0;
+            v->graphs[lru].seen = 0;
+            v->graphs[lru].launched = false;
+        }
         size_t in_use = 0;
         for (const parrot_voc::Graph& q : v->graphs) in_use += q.mem_bytes;
-        bool ok = in_use + off <= parrot_voc::MAX_GRAPH_BYTES && hipMalloc((void**)&g->mem, off) == hipSuccess;
+        if (in_use + off > cap) {  // larger than the whole cap: direct, and not asked again for a while
+            g->seen = -1000;
+            lk.unlock();
+            return direct();
+        }
+        bool ok = hipMalloc((void**)&g->mem, off) == hipSuccess;
         if (ok) {
             g->mem_bytes = off;
             g->code = reinterpret_cast<int64_t*>(g->mem + o_code);
@@ -1307,6 +1352,12 @@ static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_st
                              hipMemcpyDeviceToDevice, s));
     if (g->spkr) HIP_TRY(hipMemcpyAsync(g->spkr, spkr, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     if (g->lens) HIP_TRY(hipMemcpyAsync(g->lens, unit_lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (poison_word()) {
+        TRY(poison(g->ws, g->ws_bytes, s));
+        TRY(poison(g->wav, g->wav_bytes, s));
+        TRY(poison(wav_out, g->wav_bytes, s));
+        TRY(poison(ws, ws_bytes, s));
+    }
     HIP_TRY(hipGraphLaunch(g->exec, s));
     HIP_TRY(hipMemcpyAsync(wav_out, g->wav, g->wav_bytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipEventRecord(g->done, s));
@@ -1371,6 +1422,10 @@ extern "C" int parrot_voc_forward_chunked(parrot_voc_t* v, const int64_t* code, 
     hipStream_t s = (hipStream_t)stream;
     const int n_chunks = (U + chunk_units - 1) / chunk_units;
     const int n_lanes = std::min(chunk_lanes(), n_chunks);
+    if (poison_word()) {
+        TRY(poison(ws, ws_bytes, s));
+        TRY(poison(wav_out, (size_t)B * U * hop * sizeof(float), s));
+    }
     // lanes run WITHOUT the MRF branch streams (whole chunks overlap better than the branches of one); a call on one lane only -- a
     // single chunk, PARROT_CHUNK_LANES=1 -- keeps the branch streams of its shape, like parrot_voc_forward on that span
     const int ns_chunk = n_lanes > 1 ? 1 : voc_streams(v, B, span);
@@ -1946,7 +2001,7 @@ static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t
     TRY(conv_launch(t->dp1.get(), w.n, nullptr, w.f, B, S, EPI_STORE, 1.f, 0, 0, 0, s, src_len));
     TRY(layernorm(w.f, t->ln1_w, t->ln1_b, w.n, B, NF, S, 1, s));
     TRY(conv_launch(t->dp_proj.get(), w.n, nullptr, w.o, B, S, EPI_STORE, 1.f, 0, 0, 0, s));  // (B,1,S)
-    hipLaunchKernelGGL(duration_kernel, dim3(B), dim3(256), 0, s, w.o, src_mask, log_dur, dur, st.cum, st.out_len, S);
+    hipLaunchKernelGGL(duration_kernel, dim3(B), dim3(256), 0, s, w.o, src_mask, log_dur, dur, st.cum, st.out_len, S, src_len);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_lens, st.out_len, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return PARROT_OK;
@@ -1954,6 +2009,14 @@ static int tte_encode_rows(parrot_tte_t* t, const int64_t* phones, const uint8_t
 extern "C" int parrot_tte_encode(parrot_tte_t* t, const int64_t* phones, const uint8_t* src_mask, const int64_t* speaker,
                                  const int32_t* src_len, int32_t B, int32_t S, float* log_dur, int64_t* dur, int32_t* out_lens, void* state,
                                  size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+    if (poison_word() && B > 0 && S > 0) {
+        hipStream_t s = (hipStream_t)stream;
+        TRY(poison(state, state_bytes, s));
+        TRY(poison(ws, ws_bytes, s));
+        TRY(poison(log_dur, (size_t)B * S * sizeof(float), s));
+        TRY(poison(dur, (size_t)B * S * sizeof(int64_t), s));
+        TRY(poison(out_lens, (size_t)B * sizeof(int32_t), s));
+    }
     return tte_encode_rows(t, phones, src_mask, speaker, src_len, B, S, 0, B, log_dur, dur, out_lens, state, state_bytes, ws, ws_bytes, stream);
 }
 
@@ -2020,6 +2083,13 @@ static int tte_decode_rows(parrot_tte_t* t, int32_t Bfull, int32_t S, int32_t L,
 }
 extern "C" int parrot_tte_decode(parrot_tte_t* t, int32_t B, int32_t S, int32_t L, int32_t row_exact, int64_t* ids, uint8_t* tgt_mask,
                                  float* logits, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+    if (poison_word() && t && B > 0 && L > 0) {
+        hipStream_t s = (hipStream_t)stream;
+        TRY(poison(ws, ws_bytes, s));
+        TRY(poison(ids, (size_t)B * L * sizeof(int64_t), s));
+        TRY(poison(tgt_mask, (size_t)B * L, s));
+        TRY(poison(logits, (size_t)B * L * t->cfg.n_codes * sizeof(float), s));
+    }
     return tte_decode_rows(t, B, S, L, 0, B, ids, tgt_mask, logits, state, state_bytes, ws, ws_bytes, stream, 0, true, true, row_exact != 0);
 }
 
@@ -2055,6 +2125,12 @@ extern "C" int parrot_length_regulator(const float* seq, const int64_t* dur, int
     int32_t* cum = a.take<int32_t>((size_t)B * S);
     int32_t* lens = a.take<int32_t>((size_t)B);
     if (!a.ok) return fail(PARROT_E_NOMEM, "length_regulator: workspace too small");
+    if (poison_word()) {
+        TRY(poison(ws, ws_bytes, s));
+        TRY(poison(out, (size_t)B * L * D * sizeof(float), s));
+        TRY(poison(mask, (size_t)B * L, s));
+        TRY(poison(out_lens, (size_t)B * sizeof(int32_t), s));
+    }
     HIP_TRY(hipMemsetAsync(zero, 0, (size_t)D * sizeof(float), s));
     // (B,S,D) -> (B,D,S): the transpose kernel with the roles of C and T swapped
     hipLaunchKernelGGL(transpose_cf_to_cl_kernel, dim3((D + 63) / 64, (S + 63) / 64, B), dim3(256), 0, s, seq, seq_cf, S, D);

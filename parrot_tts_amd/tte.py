@@ -233,14 +233,23 @@ class Parrot(nn.Module):
         src_len = None
         if row_exact:  # real tokens per row; the key mask is that prefix (collate pads on the right, modules/data.py:97-104)
             src_len = valid.sum(1, dtype=torch.int32).contiguous()
-            valid = (torch.arange(S, device=dev)[None, :] < src_len[:, None]).to(torch.uint8).contiguous()
+            prefix = torch.arange(S, device=dev)[None, :] < src_len[:, None]
+            # a mask that is not a right-padded prefix (a pad-index token inside an utterance, left padding) has no "row alone"
+            # reading: the count would drop real trailing tokens silently.  Checked on the device; the verdict rides on the length
+            # transfer below (no extra sync) and raises there.
+            not_prefix = (prefix != valid.bool()).any().to(torch.int32).reshape(1)
+            # (a row of no tokens at all keeps key 0 attendable -- a softmax over no keys is 0 / 0 -- and expands to nothing: the
+            #  duration kernel masks by src_len, not by this key mask)
+            valid = (torch.arange(S, device=dev)[None, :] < src_len.clamp(min=1)[:, None]).to(torch.uint8).contiguous()
         speaker = None
         if self.n_speaker > 1:
             speaker = batch["speaker"].to(dev, torch.int64).contiguous()
         log_dur = torch.empty((B, S), dtype=torch.float32, device=dev)
         dur = torch.empty((B, S), dtype=torch.int64, device=dev)
         # expanded lengths + this handle's status flag + one slot per hook: ONE device-to-host transfer fetches them all
-        status = torch.zeros((B + 1 + len(status_hooks),), dtype=torch.int32, device=dev)
+        status = torch.zeros((B + 2 + len(status_hooks),), dtype=torch.int32, device=dev)  # (last slot: the prefix check above)
+        if row_exact:
+            status[-1:] = not_prefix
         lens = status[:B]
         state = torch.empty(lib.parrot_tte_state_bytes(self._handle, B, S), dtype=torch.uint8, device=dev)
         st = stream_ptr(dev)
@@ -257,6 +266,9 @@ class Parrot(nn.Module):
             except _lib.ParrotHipError as e:
                 self._reraise(e)
         lens_h = status_h[:B]
+        if int(status_h[-1]):
+            raise ValueError("row_exact=True needs src_mask to be a right-padded prefix per row (modules/data.py:97-104 pads on the right); "
+                             "this mask has a pad inside an utterance or left padding -- run the padded-batch mode (row_exact=False) instead")
         # bad phone / speaker ids of THIS encode (the reference's Embedding IndexError), non-finite logits of the previous
         # decode, and whatever the hooks watch (the previous vocoder forward): raised here, by default, at no extra sync
         if int(status_h[B]) == 5:

@@ -18,6 +18,15 @@ from parrot_tts_amd.vocoder import AttrDict, CodeGenerator  # noqa: E402
 DEV = "cuda:0"
 
 
+def _peek_status(m):
+    """The TTE handle's device status flag, not cleared (0 ok, 5 non-finite logits, 1-4 bad ids)."""
+    from parrot_tts_amd import _lib
+    from parrot_tts_amd.ops import dptr, stream_ptr
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().parrot_tte_status_peek_async(m._handle, dptr(flag), stream_ptr(torch.device(DEV))))
+    return int(flag.cpu())
+
+
 def _gen(h, sd):
     g = CodeGenerator(AttrDict(h))
     g.load_state_dict(sd)
@@ -166,7 +175,11 @@ def test_tie_guard_reevaluates_low_margin_positions_in_fp64(tmp_path):
     sd = synth.synth_tte_state_dict(cfg, vocab, n_spk, seed=8)
     hw, hb = sd["head.weight"].clone(), sd["head.bias"].clone()
     hw[:] = hw * 0.01                       # every other code far below ...
-    hw[17] = hw[5] = torch.randn_like(hw[5])  # ... two identical rows that win everywhere
+    # ... two identical rows that win everywhere.  SEEDED, and small against the bias gap: this torch build seeds its global generator
+    # per process, and an unseeded randn row (|w.x| of a few tens) put 3 + w.x below the other codes' -50 at a few positions in ~7 %
+    # of processes -- those positions then hold no tie at all, in the oracle as much as here (profiles/r06c_tie_repro.md: the red
+    # driver run of round 5).  The precondition below states what the test needs instead of hoping for it.
+    hw[17] = hw[5] = torch.randn(hw[5].shape, generator=torch.Generator().manual_seed(17)) * 0.05
     hb[:] = -50.0
     hb[17] = hb[5] = 3.0
     sd["head.weight"], sd["head.bias"] = hw, hb
@@ -177,10 +190,22 @@ def test_tie_guard_reevaluates_low_margin_positions_in_fp64(tmp_path):
     gb = {k: v.to(DEV) for k, v in batch.items()}
     with torch.no_grad():
         ref = O.tte_forward(sd, cfg, batch)
+    top2 = ref["logits"].topk(2, -1)
+    assert bool((top2.indices.sort(-1).values == torch.tensor([5, 17])).all()) and bool((top2.values[..., 0] == top2.values[..., 1]).all()), \
+        "precondition: codes 5 and 17 tie for the maximum at every position of the oracle's logits"
     r = m.infer_dense(gb)
     gs = m.guard_stats()
     mask = ref["tgt_mask"]
-    assert gs["n_guarded"] >= int(mask.sum()) and gs["min_margin"] <= 1e-5
+    B, L = r["ids"].shape
+    # every (b, t) of the decode -- padded frames included -- sees the two identical head rows: B * L exact ties, no fewer
+    diag = {"L": L, "lens": r["lens"].tolist(), "dur_sum": r["dur"].sum(1).tolist(), "guard": gs, "flag": _peek_status(m)}
+    if gs["n_guarded"] != B * L:
+        lg = m.forward(gb, inference=True)[0].cpu()
+        top2 = lg.topk(2, -1).values
+        diag["margins"] = (top2[..., 0] - top2[..., 1]).tolist()
+        diag["nonfinite_logits"] = int((~torch.isfinite(lg)).sum())
+    assert gs["n_guarded"] == B * L and gs["min_margin"] == 0.0, diag
+    assert gs["precision_in_use"] == "f16x3", diag
     ids = r["ids"].cpu()
     assert bool((ids[mask] == 5).all()), "an exact tie goes to the FIRST maximal index (torch.argmax), here code 5"
     assert torch.equal(ids[mask], torch.argmax(ref["logits"], -1)[mask])

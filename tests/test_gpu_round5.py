@@ -125,7 +125,7 @@ def test_row_exact_batch_equals_single_utterance_reference_runs(tmp_path, size):
             assert len(got[b]) == len(ref_ids) or not dur_safe
             n_skipped += 1
     assert worst <= 2e-5
-    assert n_checked >= B // 2, (n_checked, n_skipped)
+    assert n_checked >= B - 1, (n_checked, n_skipped)  # (32 / 32 small, 31 / 32 full on the seeds above: at most one row below the margins)
     # the default mode is untouched: the reference's padded-batch result (which differs from the single-utterance one)
     with torch.no_grad():
         ref_rows = O.tte_infer(tsd, cfg, batch)
