@@ -198,9 +198,11 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-fp32 pass")
-    ap.add_argument("--overlap", type=int, default=int(os.environ.get("PARROT_BENCH_OVERLAP", "0")),
-                    help="1: the headline run itself uses the two-stage pipeline across steps (TTE of batch i on a side stream beside "
-                         "the vocoder of batch i-1); default 0: one batch at a time, the pipelined rate is reported next to it")
+    ap.add_argument("--overlap", type=int, default=int(os.environ.get("PARROT_BENCH_OVERLAP", "1")),
+                    help="1 (default since round 6): the headline run uses the two-stage pipeline across steps (TTE of batch i on a side HIP "
+                         "stream beside the vocoder of batch i-1: the throughput schedule of SynthesisPipeline.submit / flush, every batch "
+                         "submitted inside the timed region finishes inside it); 0: one batch at a time.  The other schedule's rate is "
+                         "reported next to the headline either way (`sequential_steps` / `pipelined_steps`)")
     ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "bf16", "f16"], default=os.environ.get("PARROT_BENCH_PRECISION", "f16x3"),
                     help="product evaluation of the conv kernels for layers with >= 16 channels (fp32 data either way): f16x3 (default), "
                          "bf16x6 and f32 are parity-grade; bf16 / f16 are the single-MFMA reduced-precision operating point")
@@ -554,20 +556,24 @@ def main():
         # SNR vs the fp32 reference waveform: tests/test_gpu_baseline_shapes.py (>= 35.9 dB, the reference under autocast).
         for key, prec_ in (("bf16_vocoder", "bf16"), ("f16_vocoder", "f16")):
             # as configs[2] is worded: the TTE stays fp32-class (f16x3 products, parity-grade ids), only the vocoder drops to one MFMA
-            e5, rows5, n5, _ = run(prec_, a.steps, max(a.warmup, 2), tte_precision="f16x3")
+            e5, rows5, n5, _ = run(prec_, a.steps, max(a.warmup, 2), tte_precision="f16x3", overlap_steps=bool(a.overlap))
             ms5 = e5 / a.steps * 1e3
             d5 = rows5[0]  # (the timed-region row: stages 0-1 on the 128 x 160 tile -- vocoder launches only)
             mf, hb = d5["tflops"] / MFMA16_PEAK_TFLOPS, d5["alg_gbs"] / HBM_PEAK_GBS
             res[key] = {"value": n5 / (ms5 / 1e3), "unit": "samples/s", "ms_per_step": ms5, "precision": prec_, "tte_precision": "f16x3",
-                        "note": "reduced precision (single %s MFMA per product group in the vocoder, fp32 accumulate, fp32 activations in HBM; TTE in "
-                                "the parity-grade f16x3 scheme): NOT parity-grade, companion to the headline" % prec_[:4],
+                        "schedule": "pipelined across steps" if a.overlap else "one batch at a time",
+                        "note": "reduced precision (single %s MFMA per product group in the vocoder, fp32 accumulate and fp32 residual stream; the "
+                                "layer-by-layer convs of stages 0-2 hand their activations over as pre-activated 16-bit operand planes written by "
+                                "the producer's epilogue and fetched global -> LDS without VALU work (csrc/conv_split16.h); TTE in the parity-grade "
+                                "f16x3 scheme): NOT parity-grade, companion to the headline" % prec_[:4],
                         "dominant_kernel": d5["kernel"], "dominant_tflops": d5["tflops"],
                         "roofline": {"kernel": d5["kernel"], "ms_per_step": d5["ms_per_step"], "launches_per_step": d5["launches_per_step"],
                                      "mfma": {"achieved": d5["tflops"], "peak": MFMA16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf},
-                                     "hbm": {"achieved": d5["alg_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s (algorithmic, fp32 activations)", "frac": hb},
-                                     "bound": ("hbm" if hb > mf else "mfma") + ": neither roof is reached -- the layer kernels still read fp32 "
-                                              "activations and convert every element once per consumer (5 VALU + an LDS store per element), "
-                                              "which is what bounds a chunk once the MFMAs are a third of the f16x3 scheme's"}}
+                                     "hbm": {"achieved": d5["alg_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s (algorithmic, fp32-sized activations)", "frac": hb},
+                                     "bound": ("hbm" if hb > mf else "mfma") + ": neither roof is reached -- with the conversion gone from five of the "
+                                              "six convs of a ResBlock (operand planes) a 32-channel chunk is bound by its weight fragments through "
+                                              "the vector L1 (352 KB per chunk and CU at 64 B/clk = 5.5 k clocks against 7 k clocks of MFMA) and its "
+                                              "LDS fragment reads, not by either roof (DESIGN.md section 7, round 6)"}}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             cfg, h, tsd, vsd = pieces

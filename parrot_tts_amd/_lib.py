@@ -95,6 +95,7 @@ SIGNATURES = {
     "parrot_voc_status_async": (C.c_int, [vp, vp, vp]),
     "parrot_voc_status_peek_async": (C.c_int, [vp, vp, vp]),
     "parrot_voc_receptive_units": (C.c_int, [vp]),
+    "parrot_voc_wait_stage": (C.c_int, [vp, C.c_int32, vp]),
     "parrot_voc_out_len": (C.c_int64, [vp, i32]),
     "parrot_wav_to_int16": (C.c_int, [vp, vp, sz, vp]),
     "parrot_tte_create": (C.c_int, [C.POINTER(vp), C.POINTER(TteCfg), C.POINTER(TteWeights)]),

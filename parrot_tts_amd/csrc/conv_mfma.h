@@ -98,6 +98,14 @@ struct ConvParams {
                          // transposes each 16-row tile through a wave-private LDS region and moves 16 bytes per lane and instruction
     float acc_scale;         // split schemes with pre-scaled operands (conv_split.h): the accumulator holds acc_scale * sum
     float out_scale;         // = 1 / acc_scale (both exact powers of two; 1 for every other kernel)
+    // Operand planes (conv_split16.h): an activation tensor as the CONSUMER's ready-made MFMA operand -- leaky ReLU, scale and the
+    // scheme's 16-bit split applied once by the producer's epilogue -- laid out per batch row as [piece][C / 8][T][8 x 16 bit].
+    const void* xplane;      // consumer: read the conv input from this plane instead of x (same values, no conversion in the kernel)
+    void* yplane;            // producer: also write split(pre(y)) for the next layer
+    long xplane_bstride;     // bytes between batch rows
+    long yplane_bstride;
+    float yplane_slope;      // the NEXT layer's leaky-ReLU slope (1: none)
+    int plane_only;          // producer: the fp32 output is not needed (the tensor between the two convs of a ResBlock pair)
 };
 
 // ACT_TANH (conv_post only) is applied by tanh_inplace_kernel right after the conv launch: inlining tanhf

@@ -18,9 +18,18 @@
 #pragma once
 #include "conv_split.h"
 
+// plane input (XPL instantiations): 1 = global -> LDS directly (buffer_load_dwordx4 ... lds), 0 = through registers
+// (16-byte loads, 16-byte ds_write): an A/B switch for experiment builds (tools/build_exp.sh)
+#ifndef PARROT_XPL_DMA
+#define PARROT_XPL_DMA 1
+#endif
+
 namespace parrot {
 
-template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
+// XPL: the input comes as an operand plane (ConvParams::xplane: [piece][C / 8][T][8 x 16 bit] per batch row, written by the
+// producing layer's epilogue below): the slab staging is one 16-byte load and one 16-byte LDS store per (octet, column, piece) --
+// no leaky ReLU / scale / split in this kernel, and none repeated by the M-blocks and halo columns that share an input.
+template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2, bool XPL = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kernel(const ConvParams p) {
     static_assert(K > 0, "tap count is a template parameter");
     constexpr int NPC = SCH::NP, NTERM = SCH::NT;
@@ -54,14 +63,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     const int t0 = tn0 * BN;
     const int Tlim = p.row_len ? min(p.Tin, row_true_len(p.row_len[b], p.row_len_mul, p.row_len_add)) : p.Tin;
     const int W = BN + (K - 1) * p.dil;
-    const float* __restrict__ xb = p.x + (size_t)b * p.x_bstride;
+    const char* __restrict__ xb = XPL ? reinterpret_cast<const char*>(p.xplane) + (size_t)b * p.xplane_bstride
+                                      : reinterpret_cast<const char*>(p.x + (size_t)b * p.x_bstride);
 
     // ---- slab fetch: buffer-addressed, out-of-row / out-of-reach columns read 0 (= the zero padding) ----------------
     const size_t xaddr = reinterpret_cast<size_t>(xb);
     const unsigned x_lo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), x_hi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void*>(((size_t)x_hi << 32) | x_lo), 0, 0x7fffffff, 0x00020000);
-    const int row_bytes = p.Tin * 4;
+    // (plain input: a row of one channel; plane input: a row of one channel OCTET, 16 bytes per column)
+    const int row_bytes = XPL ? p.Tin * 16 : p.Tin * 4;
+    const int xpiece_bytes = (p.Cin >> 3) * row_bytes;  // (plane input: bytes of one piece of a batch row)
     const float slope = (p.pre == PRE_LRELU) ? p.pre_slope : 1.f;
     int voff[ITEMS], soct[ITEMS];
     static_for<ITEMS>([&](auto ic) {
@@ -70,31 +82,71 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
         const int so = item / COLS;  // octet (wave-uniform: COLS is a multiple of 64)
         const int col = item - so * COLS;
         const int tin = t0 - p.pad_left + col;
-        voff[i] = (col < W && tin >= 0 && tin < Tlim) ? tin * 4 : (int)0x80000000;
-        soct[i] = __builtin_amdgcn_readfirstlane(so * 8) * row_bytes;
+        voff[i] = (col < W && tin >= 0 && tin < Tlim) ? tin * (XPL ? 16 : 4) : (int)0x80000000;
+        soct[i] = __builtin_amdgcn_readfirstlane(so * (XPL ? 1 : 8)) * row_bytes;
     });
-    float stage[ITEMS][8];
+    float stage[XPL ? 1 : ITEMS][8];
+    const u32x4 xdesc = {x_lo, x_hi, 0x7fffffffu, 0x00020000u};  // (the same descriptor as xrsrc, as four scalars for the asm below)
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw + wave * 1024);
+    // (plane input: global -> LDS without passing through registers -- buffer_load_dwordx4 ... lds writes lane l's 16 bytes to
+    //  M0 base + 16 l: a wave's 64 consecutive items are 64 consecutive columns of one octet = 1 KiB contiguous in the slab;
+    //  out-of-range lanes (padding, row ends) write zeros)
+    u32x4 pstage[(XPL && !PARROT_XPL_DMA) ? ITEMS : 1][NPC];
     auto load_slab = [&](int c) __attribute__((always_inline)) {
-        const int cbase = c * 32 * row_bytes;
-        static_for<ITEMS>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
+        if constexpr (XPL && !PARROT_XPL_DMA) {
+            const int cbase = c * 4 * row_bytes;
+            static_for<ITEMS>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                stage[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff[i], cbase + soct[i] + e * row_bytes, 0));
-        });
+                for (int pc = 0; pc < NPC; ++pc)
+                    pstage[i][pc] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff[i], cbase + soct[i] + pc * xpiece_bytes, 0);
+            });
+        } else if constexpr (XPL) {
+            // (inline asm, not __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler orders every later ds_read behind an LDS-writing
+            //  load it knows about -- a vmcnt wait in front of the CURRENT chunk's fragment reads -- and the scheduling constraints
+            //  spill registers inside the K loop (round 3 measured that consumer 27 % slower than the converting kernel); hidden
+            //  in asm the loads are just eight more VMEM instructions, published by the vmcnt(0) + barrier that ends the chunk)
+            const int cbase = c * 4 * row_bytes;
+            const unsigned dst = lds_base + (c & 1) * BUF_BYTES;
+            static_for<ITEMS>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc) {
+                    const unsigned d = dst + pc * PIECE_BYTES + NT * i * 16;
+                    const int vo = voff[i], so = cbase + soct[i] + pc * xpiece_bytes;
+                    const u32x4 xd = xdesc;
+                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(d), "v"(vo), "s"(xd), "s"(so) : "memory");
+                }
+            });
+        } else {
+            const int cbase = c * 32 * row_bytes;
+            static_for<ITEMS>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    stage[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff[i], cbase + soct[i] + e * row_bytes, 0));
+            });
+        }
     };
     auto store_slab = [&](int buf) __attribute__((always_inline)) {
         char* dst = smem_raw + buf * BUF_BYTES;
         static_for<ITEMS>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int item = tid + NT * i;
-            unsigned q[4][NPC];
+            if constexpr (XPL && !PARROT_XPL_DMA) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                SCH::split(pre_scale<SCH>(stage[i][2 * e], slope), pre_scale<SCH>(stage[i][2 * e + 1], slope), q[e]);
+                for (int pc = 0; pc < NPC; ++pc) *reinterpret_cast<u32x4*>(dst + pc * PIECE_BYTES + item * 16) = pstage[i][pc];
+            } else if constexpr (XPL) {
+                (void)dst; (void)item;  // (the loads of load_slab landed in LDS themselves; the barrier below publishes them)
+            } else {
+                unsigned q[4][NPC];
 #pragma unroll
-            for (int pc = 0; pc < NPC; ++pc)  // item = octet * COLS + column: consecutive lanes, consecutive 16-byte slots
-                *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES + item * 16) = uint4{q[0][pc], q[1][pc], q[2][pc], q[3][pc]};
+                for (int e = 0; e < 4; ++e)
+                    SCH::split(pre_scale<SCH>(stage[i][2 * e], slope), pre_scale<SCH>(stage[i][2 * e + 1], slope), q[e]);
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc)  // item = octet * COLS + column: consecutive lanes, consecutive 16-byte slots
+                    *reinterpret_cast<uint4*>(dst + pc * PIECE_BYTES + item * 16) = uint4{q[0][pc], q[1][pc], q[2][pc], q[3][pc]};
+            }
         });
     };
 
@@ -150,6 +202,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     for (int tm = 0; tm < TM; ++tm) load_a_tile(A[tm], tm, 0);
     load_slab(0);
     store_slab(0);
+    if constexpr (XPL && PARROT_XPL_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {  // one chunk = K straight-line steps
@@ -179,7 +232,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
         for (int i = 0; i < NPC * TN; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            int slab_left = (j == 0) ? ITEMS * 8 : 0;
+            int slab_left = (j == 0) ? ((XPL && PARROT_XPL_DMA) ? 0 : XPL ? ITEMS * NPC : ITEMS * 8) : 0;  // (plane input by DMA: the slab loads are asm, issued ahead of the step)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -199,6 +252,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) store_slab((c + 1) & 1);
+        // this wave's slab loads have landed in LDS: everything but the step's own weight refills (the TM * NPC youngest loads, for the
+        // next chunk's first step -- issued long after the slab loads, returns are in order) has come back
+        if constexpr (XPL && PARROT_XPL_DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * NPC) : "memory");
         __syncthreads();
     }
 
@@ -212,6 +268,81 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     const bool do_div = p.epi == EPI_ADD_DIV;
     const bool relu = p.act == ACT_RELU;
     const RowTile yt = row_tile(yb, p.M, p.Tout), rt = row_tile(late_res ? rb : yb, p.M, p.Tout);
+    if (p.yplane) {
+        // Producer of an operand plane (EPI_STORE only): y = max(acc * out_scale, relu ? 0 : -inf) + res as below, then ALSO (or
+        // only: plane_only) split(pre(y)) with the NEXT layer's leaky ReLU -- the very instructions that layer's slab staging
+        // would run on the stored fp32 value, so its MFMA operands are bit for bit the same -- as [piece][M / 8][Tout][8 x 16 bit].
+        // A lane holds 4 of an octet's 8 channels of ONE column (C/D layout); the other 4 sit in lane ^ 16: v_permlane16_swap
+        // between two tiles gives the even 16-lane rows the whole octet of the first tile and the odd rows that of the second
+        // (the fused kernels' write_p): one 16-byte store per lane and piece, 16 lanes = 256 contiguous bytes.
+        int vo[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n_wave + tn * 16 + l15;
+            vo[tn] = (n < p.Ncols) ? (4 * g4 * p.Tout + n) * 4 : (int)0x80000000;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int m0 = m_wave + tm * 16;
+            float rv[TN][4];
+            if (late_res) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rv[tn][r] = row_tile_load(rt, vo[tn], (m0 + r) * out_row_bytes);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[tm][tn][r] * p.out_scale;
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (late_res) v = v + rv[tn][r];
+                    acc[tm][tn][r] = v;
+                }
+            if (!p.plane_only) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) row_tile_store(yt, acc[tm][tn][r], vo[tn], (m0 + r) * out_row_bytes);
+            }
+        }
+        char* pbase = reinterpret_cast<char*>(p.yplane) + (size_t)b * p.yplane_bstride;
+        const size_t pa = reinterpret_cast<size_t>(pbase);
+        const unsigned p_lo = __builtin_amdgcn_readfirstlane((unsigned)pa), p_hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+        const int ypiece_bytes = (p.M >> 3) * p.Tout * 16;
+        const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((size_t)p_hi << 32) | p_lo), 0,
+                                                                                __builtin_amdgcn_readfirstlane(NPC * ypiece_bytes), 0x00020000);
+        const float nslope = p.yplane_slope;
+        constexpr bool PAIR_M = (TM % 2 == 0);  // pair row tiles (any TN), or -- one row tile per wave -- column tiles
+        static_assert(PAIR_M || TN % 2 == 0, "operand-plane epilogue: an even number of row or column tiles per wave");
+        constexpr int NA = PAIR_M ? TM / 2 : TM, NB = PAIR_M ? TN : TN / 2;
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                const int tm0 = PAIR_M ? 2 * ia : ia, tm1 = PAIR_M ? 2 * ia + 1 : ia;
+                const int tn0 = PAIR_M ? ib : 2 * ib, tn1 = PAIR_M ? ib : 2 * ib + 1;
+                unsigned qq[2][2][NPC];  // [tile of the pair][channel pair e][piece]
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    SCH::split(pre_scale<SCH>(acc[tm0][tn0][2 * e], nslope), pre_scale<SCH>(acc[tm0][tn0][2 * e + 1], nslope), qq[0][e]);
+                    SCH::split(pre_scale<SCH>(acc[tm1][tn1][2 * e], nslope), pre_scale<SCH>(acc[tm1][tn1][2 * e + 1], nslope), qq[1][e]);
+                }
+                // this lane's octet after the swap: even 16-lane rows own the first tile's, odd rows the second's
+                const int tmq = (g4 & 1) ? tm1 : tm0, tnq = (g4 & 1) ? tn1 : tn0;
+                const int oct = ((m_wave + tmq * 16) >> 3) + (g4 >> 1);
+                const int n = n_wave + tnq * 16 + l15;
+                const int off = (n < p.Ncols && oct * 8 < p.M) ? (oct * p.Tout + n) * 16 : (int)0x80000000;
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc) {
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(qq[0][0][pc], qq[1][0][pc], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(qq[0][1][pc], qq[1][1][pc], false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{r0[0], r1[0], r0[1], r1[1]}, prsrc, off, pc * ypiece_bytes, 0);
+                }
+            }
+        return;
+    }
     if (p.epi16) {
         // 16-byte epilogue: the C/D layout gives a lane ONE column of four rows, i.e. four 4-byte accesses to four different rows
         // per tile (64-80 stores, and as many loads per residual / accumulate operand, per lane: ~100 clocks of issue each beside
@@ -320,12 +451,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_split16_kern
     }
 }
 
-template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2>
+template <class SCH, int WAVES_M, int WAVES_N, int TM, int TN, int K, int MINW = 2, bool XPL = false>
 inline hipError_t launch_conv_split16_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16, COLS = (BN + CONV_HALO + 63) / 64 * 64;
     // slab double buffer, or the epilogue's wave-private staging rows ([16][TN * 16 + 4] floats per wave) where that is larger
     const size_t lds = std::max((size_t)2 * SCH::NP * 4 * COLS * 16, (size_t)WAVES_M * WAVES_N * 16 * (TN * 16 + 4) * sizeof(float));
-    auto kern = conv_split16_kernel<SCH, WAVES_M, WAVES_N, TM, TN, K, MINW>;
+    auto kern = conv_split16_kernel<SCH, WAVES_M, WAVES_N, TM, TN, K, MINW, XPL>;
     static DynLdsOnce lds_once;  // (> 64 KiB of dynamic LDS needs an explicit opt-in, per device)
     {
         hipError_t e = ensure_dyn_lds(lds_once, reinterpret_cast<const void*>(kern), (size_t)lds);
@@ -372,8 +503,15 @@ inline bool split16_has(int scheme, int k) { return (scheme == SchF16x3::ID || s
 // is fetched once and more LDS fragments are read (128 B/clk).  One utterance, stage 0, k = 11: 32.8 -> 26.2 us per launch (8 x 1
 // waves; 30.2 with 4 x 1), FFN conv 35.0 -> 24.8, stage 2 (64 x 64 tile, 4 x 1 waves) 19.1 -> 11.2; B = 1 3.11 -> 2.90 ms, B = 4
 // 3.85 -> 3.62 ms (profiles/r03r_small_tile_wave_grid_ab.txt).
+// (operand-plane input, ConvParams::xplane: the MRF's k = 7 / 11 layers only -- the XPL instantiations)
 template <class SCH>
 inline hipError_t launch_conv_split16_small_s(int variant, const ConvParams& p, hipStream_t s) {
+    if (p.xplane) {
+        if (variant == 2) return p.k == 7    ? launch_conv_split16_t<SCH, 8, 1, 1, 4, 7, 1, true>(p, s)
+                                 : p.k == 11 ? launch_conv_split16_t<SCH, 8, 1, 1, 4, 11, 1, true>(p, s) : hipErrorInvalidValue;
+        return p.k == 7 ? launch_conv_split16_t<SCH, 4, 1, 1, 4, 7, 2, true>(p, s)
+               : p.k == 11 ? launch_conv_split16_t<SCH, 4, 1, 1, 4, 11, 2, true>(p, s) : hipErrorInvalidValue;
+    }
     if (variant == 2) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 7, 1>(p, s);
             case 9: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 9, 1>(p, s);
@@ -389,6 +527,12 @@ inline hipError_t launch_conv_split16_small_s(int variant, const ConvParams& p, 
 }
 template <class SCH>
 inline hipError_t launch_conv_split16_wide_s(int variant, const ConvParams& p, hipStream_t s) {  // variants 1 and 4
+    if (p.xplane) {
+        if (variant == 4) return p.k == 7    ? launch_conv_split16_t<SCH, 2, 2, 4, 5, 7, 2, true>(p, s)
+                                 : p.k == 11 ? launch_conv_split16_t<SCH, 2, 2, 4, 5, 11, 2, true>(p, s) : hipErrorInvalidValue;
+        return p.k == 11 ? launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3, true>(p, s)
+               : p.k == 7 ? launch_conv_split16_t<SCH, 1, 4, 4, 3, 7, 2, true>(p, s) : hipErrorInvalidValue;
+    }
     if (variant == 4) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 7>(p, s);
             case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 9>(p, s);
@@ -404,6 +548,8 @@ inline hipError_t launch_conv_split16_wide_s(int variant, const ConvParams& p, h
 }
 template <class SCH>
 inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStream_t s) {  // variant 0
+    if (p.xplane) return p.k == 7    ? launch_conv_split16_t<SCH, 2, 2, 4, 4, 7, 2, true>(p, s)
+                         : p.k == 11 ? launch_conv_split16_t<SCH, 2, 2, 4, 4, 11, 2, true>(p, s) : hipErrorInvalidValue;
     switch (p.k) {
         case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 7>(p, s);
         case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 9>(p, s);

@@ -540,10 +540,23 @@ static int conv_build(parrot_conv** out, const parrot_conv_desc* d, int groups, 
     return PARROT_OK;
 }
 
+// Operand planes between conv_split16 layers (conv_split16.h): `xplane` replaces x as the input (the values are the same: the
+// producer applied this layer's own leaky ReLU / scale / split); `yplane` is written beside y -- or instead of it (plane_only) --
+// with the NEXT layer's slope.  Dense batch rows of pieces x 2 C T bytes.
+struct PlaneArgs {
+    const void* xplane = nullptr;
+    void* yplane = nullptr;
+    float yslope = 1.f;
+    int plane_only = 0;
+};
+// can layer `c` take its input from / write its output to an operand plane?  (conv_split16 plans of the MRF: k = 7 / 11)
+static bool plane_ok(const parrot_conv* c) { return c && c->mfma16 && c->prec >= 1 && (c->kk == 7 || c->kk == 11) && c->M % 16 == 0 && c->Cin % 32 == 0; }
+static size_t plane_row_bytes(int prec, int C, int T) { return (size_t)(prec == PARROT_PREC_F16X3 ? 2 : 1) * 2 * C * T; }
+
 // x_bstride / y_bstride / res_bstride in elements; <= 0 means dense.
 static int conv_launch(const parrot_conv* c, const float* x, const float* res, float* y, int B, int Tin, int epi, float div,
                        long x_bstride, long y_bstride, long res_bstride, hipStream_t s, const int32_t* row_len = nullptr,
-                       int row_len_mul = 1, int row_len_add = 0) {
+                       int row_len_mul = 1, int row_len_add = 0, const PlaneArgs* pl = nullptr) {
     if (B <= 0 || Tin <= 0) return fail(PARROT_E_INVALID, "conv_run: empty batch or sequence");
     const int Tout = c->out_len(Tin);
     if (Tout <= 0) return fail(PARROT_E_INVALID, "conv_run: sequence shorter than the kernel");
@@ -582,6 +595,13 @@ static int conv_launch(const parrot_conv* c, const float* x, const float* res, f
     p.lean = 1;  // conv_split_kernel: the buffer-addressed prologue / epilogue instantiations for plain convs (conv_lean_ok)
     p.n_cus = g_num_cus;
     p.fold_res = c->late_res ? 0 : 1;
+    if (pl && (pl->xplane || pl->yplane)) {
+        if (!plane_ok(c) || (pl->yplane && epi != EPI_STORE)) return fail(PARROT_E_INVALID, "conv_run: operand planes need a conv_split16 layer (k = 7 / 11) and EPI_STORE");
+        p.xplane = pl->xplane; p.yplane = pl->yplane;
+        p.xplane_bstride = (long)plane_row_bytes(c->prec, c->Cin, Tin);
+        p.yplane_bstride = (long)plane_row_bytes(c->prec, c->M, Tout);
+        p.yplane_slope = pl->yslope; p.plane_only = pl->plane_only;
+    }
     p.x_bstride = x_bstride > 0 ? x_bstride : (long)c->d.c_in * Tin;
     p.y_bstride = y_bstride > 0 ? y_bstride : (long)c->Cout * Tout;
     p.res_bstride = res_bstride > 0 ? res_bstride : p.y_bstride;
@@ -707,6 +727,7 @@ struct parrot_voc {
     bool odd_stage = false;            // some stage has odd kernel_size - rate: T_out = T u + 1 there (no constant hop)
     int scheme = 0;                    // PARROT_PREC_* captured at create (immutable afterwards)
     int fused = 2;                     // fused-ResBlock mode captured at create
+    bool planes = true;                // operand planes between the layer-by-layer convs of a pair (PARROT_PLANES, read at create)
     // MRF branch concurrency: the n_kernels ResBlocks of a stage are independent chains until the final sum, so each runs
     // on its own HIP stream (the caller's + side streams owned by the handle), forked / joined with events; the final
     // accumulating launches are ordered with events (sum order j = 0, 1, 2 as models.py:100-106).  One branch's
@@ -722,6 +743,12 @@ struct parrot_voc {
     static constexpr int MAX_LANES = 4;
     hipStream_t lane_stream[MAX_LANES] = {};
     hipEvent_t ev_lane_fork = nullptr, ev_lane_join[MAX_LANES] = {};
+    // stage events (parrot_voc_wait_stage): recorded on the caller's stream when stage i of a direct forward begins (after its
+    // upsampling conv), so that ANOTHER stream can start work beside a chosen part of the forward -- the two-stage pipeline across
+    // batches runs the next batch's TTE beside the LDS-resident stage 3 / 4 kernels (one workgroup per CU, barrier waits to fill)
+    // instead of beside the chip-filling stage 0 / 1 layer convs
+    hipEvent_t ev_stage[PARROT_MAX_STAGES] = {};
+    bool capturing = false;            // (a graph capture is in progress on cap_stream: no event records into it)
     float* dbg_absmax = nullptr;       // parrot_voc_debug_absmax: (n_stages + 2) device floats, max |conv input| per group (caller-owned)
     // HIP-graph replay of small forwards (PARROT_VOC_GRAPH, default on; B x U <= 8192 units): a forward is ~130 dependent launches
     // of 7-40 us on up to three streams -- at one utterance the fork / join events and the launch gaps are a fifth of it.  A SHAPE
@@ -774,6 +801,8 @@ struct parrot_voc {
         for (hipStream_t st : lane_stream)
             if (st) (void)hipStreamDestroy(st);
         if (ev_lane_fork) (void)hipEventDestroy(ev_lane_fork);
+        for (hipEvent_t e : ev_stage)
+            if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_lane_join)
             if (e) (void)hipEventDestroy(e);
         for (uint16_t* q : rb_stream)
@@ -832,6 +861,12 @@ static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const 
     query_device();
     v->scheme = create_prec();
     v->fused = create_fused();
+    {   // operand planes: default ON for the single-piece schemes (bf16 / f16: -0.4 ms of 11.1 per step, the configs[2] data path),
+        // OFF for fp16x3 (bit-identical, but +-0: co-resident workgroups already hide the conversion, profiles/r06h_planes_ab.txt);
+        // PARROT_PLANES=0 / 1 forces either
+        const char* e = getenv("PARROT_PLANES");
+        v->planes = e ? atoi(e) != 0 : (v->scheme == PARROT_PREC_BF16 || v->scheme == PARROT_PREC_F16);
+    }
     {
         const char* e = getenv("PARROT_MRF_STREAMS");
         // default "auto": concurrent branches for small batches (B = 1 ... 16: -6 ... -11 % per batch: their launches do not
@@ -1333,7 +1368,9 @@ static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_st
         hipGraph_t graph = nullptr;
         if (ok) ok = hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
+            v->capturing = true;
             const int rc = voc_forward_impl(v, g->code, U, g->spkr, nullptr, 0, g->lens, B, U, g->wav, nullptr, g->ws, g->ws_bytes, (void*)v->cap_stream);
+            v->capturing = false;
             const hipError_t e_end = hipStreamEndCapture(v->cap_stream, &graph);
             ok = rc == PARROT_OK && e_end == hipSuccess && graph && hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess;
         }
@@ -1363,6 +1400,19 @@ static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_st
     HIP_TRY(hipEventRecord(g->done, s));
     g->last = s;
     g->launched = true;
+    return PARROT_OK;
+}
+
+// Make `stream` wait until the most recently ENQUEUED direct forward of this handle has reached stage `stage` (its upsampling conv
+// is done, its MRF begins).  The first call for a stage creates its event: forwards enqueued before that call are not waited for
+// (no-op), nor are graph replays (small shapes) -- a caller that overlaps work with the forward loses the delay, never correctness.
+extern "C" int parrot_voc_wait_stage(parrot_voc_t* v, int32_t stage, void* stream) {
+    if (!v || stage < 0 || stage >= v->cfg.n_stages) return fail(PARROT_E_INVALID, "voc_wait_stage: stage out of range");
+    if (!v->ev_stage[stage]) {
+        HIP_TRY(hipEventCreateWithFlags(&v->ev_stage[stage], hipEventDisableTiming));
+        return PARROT_OK;
+    }
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, v->ev_stage[stage], 0));
     return PARROT_OK;
 }
 
@@ -1552,6 +1602,7 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
         mul *= c.upsample_rates[i];
         add = add * c.upsample_rates[i] + ((c.upsample_kernel_sizes[i] - c.upsample_rates[i]) & 1);  // out_len(n mul + add)
         const size_t n_act = (size_t)B * v->chan(i) * T;
+        if (v->ev_stage[i] && !v->capturing) HIP_TRY(hipEventRecord(v->ev_stage[i], s));
         TRY(snap(1 + 2 * i, X, n_act));
         // every branch of the stage in ONE launch -- when that launch fills the chip twice over (one 512-thread workgroup per CU
         // walks 18 convs: a few windows are faster as per-branch launches on the branch streams; same bits either way at 32 channels)
@@ -1588,18 +1639,35 @@ static int voc_forward_impl(parrot_voc_t* v, const int64_t* code, int code_strid
             } else if (resblock_fusable(v, i, j)) {
                 TRY(resblock_fused_launch(v, i, j, X, XS, B, T, epi_last, (float)nk, sj, unit_lens, mul, add, order));
             } else {
+                // Operand planes (conv_split16.h; PARROT_PLANES=0 switches them off): the tensor between the two convs of a pair
+                // exists only as the second conv's ready-made operand -- written once by the first conv's epilogue, the same
+                // bytes per element as the fp32 tensor it replaces (two fp16 pieces), bit-identical operands -- and, in the
+                // single-piece modes (bf16 / f16: 2 bytes per element), each pair's output is written as a plane beside the
+                // fp32 residual, so that the next pair's first conv converts nothing either.
+                bool planes = v->planes && !v->dbg_absmax && c.resblock_type == 1;
+                for (int q = 0; q < per_rb && planes; ++q) planes = plane_ok(v->rb[base + q].get());
+                const bool dual = planes && v->scheme != PARROT_PREC_F16X3;  // (one piece: the two planes share T1's 4 C T bytes per row)
+                char* const plane_a = reinterpret_cast<char*>(T1);
+                char* const plane_b = plane_a + (size_t)B * plane_row_bytes(v->scheme, v->chan(i), T);
+                const void* xin = nullptr;  // plane of `r` for the next first conv (dual mode)
                 for (int m = 0; m < nd; ++m) {
                     const bool last = (m == nd - 1);
                     float* dst = last ? XS : ((m & 1) ? RB : RA);
                     if (m > 0) TRY(amax(1 + i, r, n_act, sj));
                     if (c.resblock_type == 1) {
-                        TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, sj, unit_lens, mul, add));
+                        PlaneArgs pa;
+                        pa.xplane = xin;
+                        if (planes) { pa.yplane = plane_a; pa.plane_only = 1; pa.yslope = v->rb[base + 2 * m + 1]->d.pre_act == PRE_LRELU ? v->rb[base + 2 * m + 1]->d.pre_slope : 1.f; }
+                        TRY(conv_launch(v->rb[base + 2 * m].get(), r, nullptr, T1, B, T, EPI_STORE, 1.f, 0, 0, 0, sj, unit_lens, mul, add, planes ? &pa : nullptr));
                         TRY(amax(1 + i, T1, n_act, sj));
                     }
                     if (last && order) HIP_TRY(hipStreamWaitEvent(sj, order, 0));
-                    if (c.resblock_type == 1)
-                        TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul, add));
-                    else
+                    if (c.resblock_type == 1) {
+                        PlaneArgs pa;
+                        if (planes) pa.xplane = plane_a;
+                        if (dual && !last) { pa.yplane = plane_b; pa.yslope = v->rb[base + 2 * m + 2]->d.pre_act == PRE_LRELU ? v->rb[base + 2 * m + 2]->d.pre_slope : 1.f; xin = plane_b; }
+                        TRY(conv_launch(v->rb[base + 2 * m + 1].get(), T1, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul, add, planes ? &pa : nullptr));
+                    } else
                         TRY(conv_launch(v->rb[base + m].get(), r, r, dst, B, T, last ? epi_last : EPI_STORE, (float)nk, 0, 0, 0, sj, unit_lens, mul, add));
                     r = dst;
                 }

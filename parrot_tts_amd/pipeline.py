@@ -25,6 +25,9 @@ class SynthesisPipeline:
         self.row_exact = bool(row_exact)
         self._side: Optional[torch.cuda.Stream] = None
         self._pending: Optional[dict] = None
+        # `submit`: the next batch's TTE starts when the previous batch's vocoder reaches this MRF stage (PARROT_PIPE_STAGE; -1: at once)
+        import os
+        self.pipe_stage = int(os.environ.get("PARROT_PIPE_STAGE", "2"))
 
     def _emitted(self, r, L):
         """ids per row as ``Parrot.infer`` returns them, on the host and on the device: len + 1 clamped to L in the padded-batch
@@ -76,6 +79,12 @@ class SynthesisPipeline:
         done = self._vocode_pending(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(inputs_ready)
+            # ... and beside WHICH part of that vocoder (profiles/r06j_pipe_stage_ab.txt, B = 64, one box; one batch at a time: 18.41 ms):
+            # at once 17.63 ms, with the stage 0 / 1 layer convs 19 % slower per launch while the TTE shares their CUs; from stage 2 on
+            # 17.65-17.74 ms with those launches undisturbed (228 us, as alone); from stage 3 18.03, from stage 4 18.37 -- too late: the
+            # TTE's own critical path (encoder, the length round trip, decoder) no longer fits beside what is left of the vocoder
+            if done is not None and self.pipe_stage >= 0:
+                self.generator.wait_stage(self.pipe_stage, self._side)
             # (no vocoder status hook here: this TTE runs on a side stream BESIDE the previous batch's vocoder, and the hook's
             #  read-and-clear of the flag would race with that forward; `check()` covers the pipelined schedule)
             r = self.parrot.infer_dense(batch, row_exact=self.row_exact)  # (its host sync for L waits on the side stream only)

@@ -395,6 +395,12 @@ class CodeGenerator(nn.Module):
         self._current_handle(dev)
         return int(_lib.lib().parrot_voc_receptive_units(self._handle))
 
+    def wait_stage(self, stage: int, stream: "torch.cuda.Stream") -> None:
+        """Make ``stream`` wait until the most recently enqueued forward has reached MRF stage ``stage`` (see
+        ``parrot_voc_wait_stage``).  No-op before the first forward."""
+        if self._handle is not None and 0 <= stage < len(self._rates):
+            _lib.check(_lib.lib().parrot_voc_wait_stage(self._handle, int(stage), C.c_void_p(stream.cuda_stream)))
+
     def _status_hook(self, dst_ptr: int, stream: int):
         """Enqueue a copy of this handle's device status flag (bad ids / non-finite waveform of EARLIER forwards) to ``dst_ptr``
         without synchronising: `Parrot._run` fetches it together with the expanded lengths.  Returns (name, on_nonfinite): the

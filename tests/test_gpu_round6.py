@@ -217,3 +217,22 @@ def test_graph_replay_on_ragged_batches_after_eviction():
                 y = g(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV), unit_lens=lens.to(DEV))
             torch.cuda.synchronize()
             assert torch.equal(y, ref), (sweep, B, U)
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "bf16"])
+def test_operand_planes_do_not_change_a_bit(prec):
+    """Operand planes (csrc/conv_split16.h: the first conv of a layer-by-layer ResBlock pair writes its output as the second conv's
+    ready-made MFMA operand -- leaky ReLU, scale, 16-bit split applied once in the producer's epilogue -- and, in the single-piece
+    bf16 mode of BASELINE configs[2], every pair also writes its output's plane beside the fp32 residual; the consumers fetch their
+    slabs with `buffer_load_dwordx4 ... lds`, no VALU).  The operands are bit for bit what the consumer's own conversion would have
+    produced, so the waveforms of dense, ragged and tiny launches (large, 64-row and small-tile instantiations) hash the same with
+    the planes on and off, in the parity-grade scheme (planes off by default there) and in bf16 (on by default)."""
+    def hashes(planes):
+        e = dict(os.environ)
+        e.update({"PARROT_PLANES": planes, "PARROT_PRECISION": prec})
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wav_hash.py"), "--quick"], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+    off, on = hashes("0"), hashes("1")
+    assert len(off.strip().splitlines()) == 3
+    assert on == off
