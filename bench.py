@@ -245,11 +245,18 @@ def main():
 
         gather_ev = []  # (start, stop) CUDA events around every gather: the collective's share of a step, reported as gather_ms
 
+        gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+
         def gather(wav):
+            # the collective runs on its OWN stream behind the vocoder that produced `wav`: the next batch's TTE and vocoder do not
+            # queue behind it (xGMI traffic beside compute); the closing fence of the region waits for every stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = pdist.gather_waveforms(wav, dst=0, equal_shapes=True)  # forced durations: every shard is (B, 1, 320 L)
-            e1.record()
+            gather_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(gather_stream):
+                e0.record()
+                r = pdist.gather_waveforms(wav, dst=0, equal_shapes=True)  # forced durations: every shard is (B, 1, 320 L)
+                e1.record()
+            wav.record_stream(gather_stream)
             gather_ev.append((e0, e1))
             return r
 
@@ -379,8 +386,11 @@ def main():
         cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
         vb = {k: v.to(dev) for k, v in synth.synth_voc_batch(B, U, h, seed=3).items()}
         out = {}
+        halo = gen.receptive_units(dev)
         for name, fn in (("whole", lambda: gen(code=vb["code"], spkr=vb["spkr"])),
-                         ("chunk_streamed_256", lambda: gen.forward_chunked(chunk_units=chunk, code=vb["code"], spkr=vb["spkr"]))):
+                         ("chunk_streamed_256", lambda: gen.forward_chunked(chunk_units=chunk, code=vb["code"], spkr=vb["spkr"])),
+                         ("chunk_streamed_512", lambda: gen.forward_chunked(chunk_units=512, code=vb["code"], spkr=vb["spkr"])),
+                         ("chunk_streamed_768", lambda: gen.forward_chunked(chunk_units=768, code=vb["code"], spkr=vb["spkr"]))):
             fn()
             fence()
             t0 = time.perf_counter()
@@ -389,7 +399,14 @@ def main():
             fence()
             ms = (time.perf_counter() - t0) / steps * 1e3
             out[name] = {"value": B * w.shape[-1] / (ms / 1e3), "unit": "samples/s", "ms_per_step": ms}
-        out["workload"] = "HiFi-GAN generator, batch %d x %d units (30 s utterances), whole and in %d-unit chunks with a 20-unit halo (BASELINE configs[4])" % (B, U, chunk)
+        # units computed per utterance incl. the halo recompute (every interior chunk boundary costs the receptive field twice): the
+        # floor of a chunked forward that stays EQUAL to the whole-utterance one, as a ratio to `whole`
+        for c_ in (256, 512, 768):
+            nb = (U + c_ - 1) // c_ - 1
+            out["chunk_streamed_%d" % c_]["units_computed_ratio"] = (U + 2 * halo * nb) / U
+            out["chunk_streamed_%d" % c_]["vs_whole"] = out["chunk_streamed_%d" % c_]["ms_per_step"] / out["whole"]["ms_per_step"]
+        out["workload"] = ("HiFi-GAN generator, batch %d x %d units (30 s utterances), whole and in 256- / 512- / 768-unit chunks with the generator's "
+                           "receptive field (%d units) of real context on both sides (BASELINE configs[4]); two chunks in flight" % (B, U, halo))
         del parrot, gen
         return out
 

@@ -125,6 +125,7 @@ def gather_waveforms(wav: torch.Tensor, dst: int = 0, equal_shapes: bool = False
 
 
 _gather_mode = os.environ.get("PARROT_GATHER", "auto")  # auto | gather | allgather
+_gather_latched = False  # "gather" was reached by the ranks' agreement in auto mode (not forced through the environment)
 GATHER_FATAL_EXIT_CODE = 70  # exit status of a rank whose latched gather failed (see _collect)
 _allgather_buf: Dict[tuple, torch.Tensor] = {}
 
@@ -134,7 +135,7 @@ def _collect(send: torch.Tensor, out, dst: int, key) -> None:
     contiguous buffer (grouped send / recv under RCCL: each peer uses its own xGMI link to the root).  Should a backend
     reject the view list, PARROT_GATHER=auto falls back -- once, for the rest of the process, on all ranks together -- to
     `all_gather_into_tensor` on a single contiguous tensor (every rank then holds a copy: world x 21 MB at B = 64)."""
-    global _gather_mode
+    global _gather_mode, _gather_latched
     world, rank = dist.get_world_size(), dist.get_rank()
     if _gather_mode == "gather":
         # Latched (or forced) mode: no per-step agreement any more, so an error on ONE rank (a new shape, OOM, a backend hiccup)
@@ -144,9 +145,14 @@ def _collect(send: torch.Tensor, out, dst: int, key) -> None:
         try:
             dist.gather(send, out, dst=dst)
         except RuntimeError as e:
-            if os.environ.get("PARROT_GATHER_FATAL", "exit") == "raise":
+            # default: end the process only under a launcher that tears the group down (torchrun sets TORCHELASTIC_RUN_ID) and only
+            # when the mode was LATCHED by an earlier agreement; a user-forced PARROT_GATHER=gather, a notebook or a bare
+            # single-node session gets the exception (atexit handlers, finally blocks and buffered output intact)
+            fatal = os.environ.get("PARROT_GATHER_FATAL") or ("exit" if (_gather_latched and os.environ.get("TORCHELASTIC_RUN_ID")) else "raise")
+            if fatal == "raise":
                 raise
             import sys
+            sys.stdout.flush()
             print(f"parrot_tts_amd.dist: rank {rank}: dist.gather failed after the gather mode was latched ({e}); the peers are "
                   "inside the collective -- ending this process so that the launcher tears the group down", file=sys.stderr, flush=True)
             os._exit(GATHER_FATAL_EXIT_CODE)
@@ -163,7 +169,7 @@ def _collect(send: torch.Tensor, out, dst: int, key) -> None:
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_meta_pg())
         if int(flag) == 1:
-            _gather_mode = "gather"
+            _gather_mode, _gather_latched = "gather", True
             return
         _gather_mode = "allgather"
         if rank == 0:

@@ -130,6 +130,7 @@ def test_single_process_is_a_no_op():
 def _worker_fail_after_latch(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ["TORCHELASTIC_RUN_ID"] = "test"  # as under torchrun: a launcher that ends the peers when one rank exits
     from parrot_tts_amd import dist as pdist
     pdist.init_from_env("gloo")
     wav = torch.full((2, 1, 8), float(rank))
