@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PARROT_ABI_VERSION 6
+#define PARROT_ABI_VERSION 7  /* 7: parrot_voc_wait_stage */
 
 enum {
     PARROT_OK = 0,

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARROT_HIP_LIB") or os.path.join(HERE, "libparrot_hip.so")
 
 MAX_STAGES, MAX_KERNELS, MAX_DIL = 8, 4, 4
-ABI_VERSION = 6  # PARROT_ABI_VERSION of include/parrot_hip.h
+ABI_VERSION = 7  # PARROT_ABI_VERSION of include/parrot_hip.h
 c_float_p = C.POINTER(C.c_float)
 
 
