@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_basics(lib):
-    assert lib.parrot_abi_version() == 6
+    assert lib.parrot_abi_version() == 7
     assert lib.parrot_conv_num_tile_cfgs() >= 3
     assert isinstance(lib.parrot_last_error(), bytes)
     # argument validation happens before any HIP call
