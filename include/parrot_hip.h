@@ -76,21 +76,16 @@ typedef struct {
  *   PARROT_PREC_BF16 / PARROT_PREC_F16   operands rounded once to bf16 / fp16, ONE MFMA per product group, fp32
  *                      accumulate, fp32 residual stream: the reduced-precision operating point (BASELINE configs[2]
  *                      "bf16"); NOT parity-grade -- reported by SNR against the fp32 result (36 dB / 54 dB).
- * The process-wide default (PARROT_PRECISION env: "f32" | "f16x3" | "bf16x6" | "bf16" | "f16", else f16x3; or the setter)
+ * The process-wide default (PARROT_PRECISION env: "f32" | "f16x3" | "bf16x6" | "bf16" | "f16", else f16x3)
  * is read ONCE by every *_create: a handle keeps the mode it was created under and is immutable afterwards. */
 #define PARROT_PREC_F32 0
 #define PARROT_PREC_BF16X6 1
 #define PARROT_PREC_F16X3 2
 #define PARROT_PREC_BF16 3
 #define PARROT_PREC_F16 4
-int parrot_set_default_precision(int32_t prec);
-/* Fused ResBlock kernels (csrc/resblock_split.h, resblock_fused.h): 0 off (layer by layer), 1 every eligible stage,
- * 2 (default; env PARROT_FUSED) all but the exact-fp32 32-channel kernel.  Default for handles created afterwards. */
-int parrot_set_fused_resblocks(int32_t mode);
-/* FFT blocks project twice on each side of the attention core (quirk Q3, modules/fft.py:48-57: qkv then MHA in_proj; MHA
- * out_proj then wo; all bias-free).  1 (default; env PARROT_TTE_MERGE): each pair is evaluated as its fp64-formed product, one
- * launch; 0: one after the other as the reference does.  Default for handles created afterwards. */
-int parrot_set_tte_merge(int32_t on);
+/* (Per handle: parrot_voc_create_ex / parrot_tte_create_ex / parrot_conv_desc.precision.  The process-wide DEFAULTS -- precision,
+ * fused ResBlock kernels (env PARROT_FUSED: 0 off, 1 every eligible stage, 2 default), merged TTE projections (env PARROT_TTE_MERGE) --
+ * come from the environment; their setters are test / bench conveniences and live in parrot_hip_debug.h.) */
 
 int parrot_conv_create(parrot_conv_t** out, const parrot_conv_desc* d, const float* w_host, const float* bias_host);
 void parrot_conv_destroy(parrot_conv_t*);

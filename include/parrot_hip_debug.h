@@ -17,6 +17,16 @@ int parrot_selftest(void* stream);
 int parrot_conv_num_tile_cfgs(void);
 
 /* dst[i] = src[i], 4 bytes per lane: known-byte-count kernel for calibrating the HBM PMC counters. */
+/* Process-wide DEFAULTS for handles created afterwards (tests and benches that build several handles under different modes in one
+ * process; a product passes the mode per handle to *_create_ex).  Read once by every *_create; a live handle never changes. */
+int parrot_set_default_precision(int32_t prec);
+/* Fused ResBlock kernels (csrc/resblock_split.h, resblock_fused.h): 0 off (layer by layer), 1 every eligible stage,
+ * 2 (default; env PARROT_FUSED) all but the exact-fp32 32-channel kernel.  Default for handles created afterwards. */
+int parrot_set_fused_resblocks(int32_t mode);
+/* FFT blocks project twice on each side of the attention core (quirk Q3, modules/fft.py:48-57: qkv then MHA in_proj; MHA
+ * out_proj then wo; all bias-free).  1 (default; env PARROT_TTE_MERGE): each pair is evaluated as its fp64-formed product, one
+ * launch; 0: one after the other as the reference does.  Default for handles created afterwards. */
+int parrot_set_tte_merge(int32_t on);
 int parrot_debug_copy(const float* src, float* dst, size_t n, void* stream);
 /* Measurement aid (bench.py `roofline.ceiling_probe_tflops`): the rate a bare fp16 MFMA stream sustains on this device under
  * its power limit -- shape 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16; random operands (constant_data = 0) or one
