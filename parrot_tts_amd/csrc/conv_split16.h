@@ -539,6 +539,8 @@ inline hipError_t launch_conv_split16_wide_s(int variant, const ConvParams& p, h
             case 11: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 11>(p, s);
             default: return hipErrorInvalidValue;
         }
+    // (round 6: the same 64 x 128 tile as 1 x 2 waves of 64 x 64 in 128-thread workgroups -- half the LDS fragment reads per MFMA, 6
+    //  waves per CU instead of 12 -- is bit-identical and SLOWER: 421 / 468 vs 347 / 389 us per launch, profiles/EXPERIMENTS.md)
     if (p.k == 11) return launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3>(p, s);
     switch (p.k) {
         case 7: return launch_conv_split16_t<SCH, 1, 4, 4, 3, 7>(p, s);

@@ -19,7 +19,7 @@ def norm(name: str) -> str:
     m = re.match(r"(conv_split_kernel<Sch\w+,\d+,\d+,\d+,\d+,\d+),\d+(,\d+)?(,(true|false))?>", name)
     if m:
         return m.group(1) + ">"
-    m = re.match(r"(conv_split16_kernel<Sch\w+,\d+,\d+,\d+,\d+),\d+(,\d+)?>", name)
+    m = re.match(r"(conv_split16_kernel<Sch\w+,\d+,\d+,\d+,\d+),\d+(,\d+)?(,(true|false))?>", name)  # (.., taps, min waves, plane input)
     if m:
         return m.group(1) + ">"
     m = re.match(r"resblock_split_kernel<(Sch\w+),(\d+),(\d+),(true|false)>", name)  # (scheme, chunks, column groups, whole-MRF)
