@@ -179,8 +179,8 @@ int parrot_voc_status_async(parrot_voc_t*, int32_t* dst_dev, void* stream);
 int parrot_voc_status_peek_async(parrot_voc_t*, int32_t* dst_dev, void* stream);
 /* Make `stream` wait until the most recently enqueued (direct, non-graph) forward of this handle has reached MRF stage `stage`
  * (0 .. n_stages - 1): a caller that runs other work beside the forward -- SynthesisPipeline.submit: the next batch's TTE, reference
- * inference.py + utils/vocoder/inference.py back to back -- chooses which part of the forward it shares the chip with.  The first
- * call for a stage only arms its event (returns without a wait). */
+ * inference.py + utils/vocoder/inference.py back to back -- chooses which part of the forward it shares the chip with.  Before the
+ * handle's first forward (and after a graph replay of a small shape) there is nothing to wait for: the call returns at once. */
 int parrot_voc_wait_stage(parrot_voc_t*, int32_t stage, void* stream);
 /* Receptive field of the generator in units, either side of an output frame, from the handle's configuration (interval
  * propagation through conv_post, the MRF stages, the transposed convs of reference utils/vocoder/models.py:80-83 and conv_pre):

@@ -861,6 +861,7 @@ static int voc_create_body(parrot_voc_t** out, const parrot_voc_cfg* cfg, const 
     query_device();
     v->scheme = create_prec();
     v->fused = create_fused();
+    for (int i = 0; i < cfg->n_stages; ++i) HIP_TRY(hipEventCreateWithFlags(&v->ev_stage[i], hipEventDisableTiming));
     {   // operand planes: default ON for the single-piece schemes (bf16 / f16: -0.4 ms of 11.1 per step, the configs[2] data path),
         // OFF for fp16x3 (bit-identical, but +-0: co-resident workgroups already hide the conversion, profiles/r06h_planes_ab.txt);
         // PARROT_PLANES=0 / 1 forces either
@@ -1404,15 +1405,13 @@ static int voc_forward_graphed(parrot_voc_t* v, const int64_t* code, int code_st
 }
 
 // Make `stream` wait until the most recently ENQUEUED direct forward of this handle has reached stage `stage` (its upsampling conv
-// is done, its MRF begins).  The first call for a stage creates its event: forwards enqueued before that call are not waited for
-// (no-op), nor are graph replays (small shapes) -- a caller that overlaps work with the forward loses the delay, never correctness.
+// is done, its MRF begins; the events are created with the handle and recorded by every direct forward).  Before the first forward,
+// and for graph replays (small shapes), there is nothing to wait for -- a caller that overlaps work with the forward loses the
+// delay, never correctness.
 extern "C" int parrot_voc_wait_stage(parrot_voc_t* v, int32_t stage, void* stream) {
     if (!v || stage < 0 || stage >= v->cfg.n_stages) return fail(PARROT_E_INVALID, "voc_wait_stage: stage out of range");
-    if (!v->ev_stage[stage]) {
-        HIP_TRY(hipEventCreateWithFlags(&v->ev_stage[stage], hipEventDisableTiming));
-        return PARROT_OK;
-    }
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, v->ev_stage[stage], 0));
+    if (!v->ev_stage[stage]) return PARROT_OK;
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, v->ev_stage[stage], 0));  // (never recorded yet: no wait)
     return PARROT_OK;
 }
 
