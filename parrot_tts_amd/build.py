@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # that the first step of every chunk waits a full fetch latency (tools/isa_schedule.py shows it in the ISA).  Without the pass
 # they stay where they are written: conv_split16 128 x 128: 6.88 -> 6.78 ms per step (mean of five same-box A/B pairs, the
 # sign held in four, one tie: at the edge of the run-to-run noise), no spills, nothing else moves.
-TU_FLAGS = {f: ["-mllvm", "-disable-machine-sink"] for f in ("tu_split16.hip", "tu_split16_wide.hip")}
+TU_FLAGS = {f: ["-mllvm", "-disable-machine-sink"] for f in ("tu_split16.hip", "tu_split16_wide.hip", "tu_split16_xpl.hip")}
 
 
 def _stale() -> bool:

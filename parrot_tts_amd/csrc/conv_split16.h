@@ -503,15 +503,8 @@ inline bool split16_has(int scheme, int k) { return (scheme == SchF16x3::ID || s
 // is fetched once and more LDS fragments are read (128 B/clk).  One utterance, stage 0, k = 11: 32.8 -> 26.2 us per launch (8 x 1
 // waves; 30.2 with 4 x 1), FFN conv 35.0 -> 24.8, stage 2 (64 x 64 tile, 4 x 1 waves) 19.1 -> 11.2; B = 1 3.11 -> 2.90 ms, B = 4
 // 3.85 -> 3.62 ms (profiles/r03r_small_tile_wave_grid_ab.txt).
-// (operand-plane input, ConvParams::xplane: the MRF's k = 7 / 11 layers only -- the XPL instantiations)
 template <class SCH>
 inline hipError_t launch_conv_split16_small_s(int variant, const ConvParams& p, hipStream_t s) {
-    if (p.xplane) {
-        if (variant == 2) return p.k == 7    ? launch_conv_split16_t<SCH, 8, 1, 1, 4, 7, 1, true>(p, s)
-                                 : p.k == 11 ? launch_conv_split16_t<SCH, 8, 1, 1, 4, 11, 1, true>(p, s) : hipErrorInvalidValue;
-        return p.k == 7 ? launch_conv_split16_t<SCH, 4, 1, 1, 4, 7, 2, true>(p, s)
-               : p.k == 11 ? launch_conv_split16_t<SCH, 4, 1, 1, 4, 11, 2, true>(p, s) : hipErrorInvalidValue;
-    }
     if (variant == 2) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 7, 1>(p, s);
             case 9: return launch_conv_split16_t<SCH, 8, 1, 1, 4, 9, 1>(p, s);
@@ -527,12 +520,6 @@ inline hipError_t launch_conv_split16_small_s(int variant, const ConvParams& p, 
 }
 template <class SCH>
 inline hipError_t launch_conv_split16_wide_s(int variant, const ConvParams& p, hipStream_t s) {  // variants 1 and 4
-    if (p.xplane) {
-        if (variant == 4) return p.k == 7    ? launch_conv_split16_t<SCH, 2, 2, 4, 5, 7, 2, true>(p, s)
-                                 : p.k == 11 ? launch_conv_split16_t<SCH, 2, 2, 4, 5, 11, 2, true>(p, s) : hipErrorInvalidValue;
-        return p.k == 11 ? launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3, true>(p, s)
-               : p.k == 7 ? launch_conv_split16_t<SCH, 1, 4, 4, 3, 7, 2, true>(p, s) : hipErrorInvalidValue;
-    }
     if (variant == 4) switch (p.k) {
             case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 7>(p, s);
             case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 5, 9>(p, s);
@@ -550,8 +537,6 @@ inline hipError_t launch_conv_split16_wide_s(int variant, const ConvParams& p, h
 }
 template <class SCH>
 inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStream_t s) {  // variant 0
-    if (p.xplane) return p.k == 7    ? launch_conv_split16_t<SCH, 2, 2, 4, 4, 7, 2, true>(p, s)
-                         : p.k == 11 ? launch_conv_split16_t<SCH, 2, 2, 4, 4, 11, 2, true>(p, s) : hipErrorInvalidValue;
     switch (p.k) {
         case 7: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 7>(p, s);
         case 9: return launch_conv_split16_t<SCH, 2, 2, 4, 4, 9>(p, s);
@@ -559,12 +544,33 @@ inline hipError_t launch_conv_split16_s(int variant, const ConvParams& p, hipStr
         default: return hipErrorInvalidValue;
     }
 }
+// operand-plane input (ConvParams::xplane: the MRF's k = 7 / 11 layers only): the XPL instantiations of every tile variant
+template <class SCH>
+inline hipError_t launch_conv_split16_xpl_s(int variant, const ConvParams& p, hipStream_t s) {
+    if (p.k != 7 && p.k != 11) return hipErrorInvalidValue;
+    const bool k7 = p.k == 7;
+    switch (variant) {
+        case 0: return k7 ? launch_conv_split16_t<SCH, 2, 2, 4, 4, 7, 2, true>(p, s) : launch_conv_split16_t<SCH, 2, 2, 4, 4, 11, 2, true>(p, s);
+        case 1: return k7 ? launch_conv_split16_t<SCH, 1, 4, 4, 3, 7, 2, true>(p, s) : launch_conv_split16_t<SCH, 2, 2, 2, 4, 11, 3, true>(p, s);
+        case 2: return k7 ? launch_conv_split16_t<SCH, 8, 1, 1, 4, 7, 1, true>(p, s) : launch_conv_split16_t<SCH, 8, 1, 1, 4, 11, 1, true>(p, s);
+        case 3: return k7 ? launch_conv_split16_t<SCH, 4, 1, 1, 4, 7, 2, true>(p, s) : launch_conv_split16_t<SCH, 4, 1, 1, 4, 11, 2, true>(p, s);
+        case 4: return k7 ? launch_conv_split16_t<SCH, 2, 2, 4, 5, 7, 2, true>(p, s) : launch_conv_split16_t<SCH, 2, 2, 4, 5, 11, 2, true>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_conv_split16_xpl_f16x3(int variant, const ConvParams& p, hipStream_t s);    // csrc/tu_split16_xpl.hip
+hipError_t launch_conv_split16_xpl_bf16(int variant, const ConvParams& p, hipStream_t s);     // csrc/tu_split16_single.hip
+hipError_t launch_conv_split16_xpl_f16(int variant, const ConvParams& p, hipStream_t s);      // csrc/tu_split16_single_f16.hip
 hipError_t launch_conv_split16_wide_f16x3(int variant, const ConvParams& p, hipStream_t s);   // csrc/tu_split16_wide.hip
 hipError_t launch_conv_split16_small_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16.hip
 hipError_t launch_conv_split16_f16x3(int variant, const ConvParams& p, hipStream_t s);  // csrc/tu_split16.hip
 hipError_t launch_conv_split16_bf16(int variant, const ConvParams& p, hipStream_t s);   // csrc/tu_split16_single.hip
 hipError_t launch_conv_split16_f16(int variant, const ConvParams& p, hipStream_t s);    // csrc/tu_split16_single.hip
 inline hipError_t launch_conv_split16(int scheme, int variant, const ConvParams& p, hipStream_t s) {
+    if (p.xplane)
+        return scheme == SchF16x3::ID ? launch_conv_split16_xpl_f16x3(variant, p, s)
+               : scheme == SchBf16::ID ? launch_conv_split16_xpl_bf16(variant, p, s)
+               : scheme == SchF16::ID  ? launch_conv_split16_xpl_f16(variant, p, s) : hipErrorInvalidValue;
     if (scheme == SchF16x3::ID)
         return (variant == 2 || variant == 3)   ? launch_conv_split16_small_f16x3(variant, p, s)
                : (variant == 1 || variant == 4) ? launch_conv_split16_wide_f16x3(variant, p, s)
