@@ -501,7 +501,10 @@ def main():
             "ms_per_step_median": head_step_ms[len(head_step_ms) // 2] if head_step_ms else None,
             "ms_per_step_min": head_step_ms[0] if head_step_ms else None, "ms_per_step_max": head_step_ms[-1] if head_step_ms else None,
             "timing": "value / ms_per_step: wall clock over the K steps between barrier + synchronize fences (max over ranks); "
-                      "ms_per_step_median: median of the K per-step HIP-event times",
+                      "ms_per_step_median: median of the K per-step HIP-event times" +
+                      ("; pipelined schedule: a step's event pair brackets what that step enqueues on its own stream, i.e. the vocoder of "
+                       "the PREVIOUS batch (the first step of the region carries none: ms_per_step_min; the last batch's vocoder runs in "
+                       "the closing flush, inside the fences)" if (a.overlap and a.workload == "full") else ""),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f16x3": "f32 (f16x3 split products)", "bf16x6": "f32 (bf16x6 split products)", "f32": "f32", "bf16": "bf16 products, f32 accumulate",
                       "f16": "f16 products, f32 accumulate"}[a.precision],
