@@ -457,6 +457,27 @@ def main():
         del parrot, gen
         return out
 
+    def b1_split(precision, steps=100):
+        """The single utterance's two halves on their own: the TTE alone (encode, the length round trip, decode:
+        ~95 launches) and the vocoder alone on the ids it produced (replayed as a HIP graph from the fourth call on)."""
+        ops.set_default_precision(ops.PREC_NAMES[precision])
+        cfg, h, tsd, vsd, parrot, gen = build_models(dev, vocab, n_spk)
+        batch = {k: v.to(dev) for k, v in synth.synth_tte_batch(1, S, vocab, n_spk, seed=0).items()}
+        r = parrot.infer_dense(batch)
+        ids, spk = r["ids"], batch["speaker"].reshape(-1, 1)
+        out = {}
+        for name, fn in (("tte_ms", lambda: parrot.infer_dense(batch)), ("vocoder_ms", lambda: gen(code=ids, spkr=spk, unit_lens=r["emitted_dev"]))):
+            for _ in range(6):
+                fn()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            fence()
+            out[name] = (time.perf_counter() - t0) / steps * 1e3
+        del parrot, gen
+        return out
+
     elapsed, rows, n_samples_step, pieces = run(a.precision, a.steps, a.warmup, overlap_steps=bool(a.overlap))
     gather_ms = run.gather_ms
     head_step_ms = list(run.step_ms)
@@ -555,10 +576,11 @@ def main():
                         "workload": "HiFi-GAN generator only, batch 32 x %d units (BASELINE configs[1])" % (4 * S),
                         "dominant_kernel": rows3[0]["kernel"], "dominant_tflops": rows3[0]["tflops"]}
         # BASELINE.json configs[0] shape: ONE utterance end to end (latency-bound: ~130 launches)
-        e4, _, n4, _ = run(a.precision, max(a.steps, 50), max(a.warmup, 3), B=1, profile=False)
+        e4, _, n4, _ = run(a.precision, max(a.steps, 50), max(a.warmup, 3), B=1, profile=False, overlap_steps=False)
         ms4 = e4 / max(a.steps, 50) * 1e3
         res["single_utterance_b1"] = {"value": n4 / (ms4 / 1e3), "unit": "samples/s", "ms_per_step": ms4, "rtf": (ms4 / 1e3) / (n4 / SAMPLE_RATE),
-                                      "workload": "full pipeline, ONE utterance (S=%d -> %d units), BASELINE configs[0] shape" % (S, 4 * S)}
+                                      "workload": "full pipeline, ONE utterance (S=%d -> %d units), BASELINE configs[0] shape" % (S, 4 * S),
+                                      "schedule": "one utterance at a time (latency: no cross-batch pipeline)", "split": b1_split(a.precision)}
         # BASELINE.json configs[4]: long-form 30 s utterances, batch 8 x 1500 units, chunk-streamed vocoder (256-unit chunks)
         res["long_form_b8_u1500"] = long_form(a.precision, min(a.steps, 5))
         # the shipped vocoder driver, batched vs one utterance per launch chain (host post-processing included)
