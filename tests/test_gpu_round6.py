@@ -300,3 +300,27 @@ def test_pipelined_schedule_with_a_stage_start_equals_sequential_calls(tmp_path,
         for row in range(w["wav"].shape[0]):
             n = int(w["n_samples"][row])
             assert torch.equal(g["wav"][row, :, :n], w["wav"][row, :, :n])
+
+
+def test_wait_stage_validates_its_arguments_and_is_a_no_op_before_the_first_forward():
+    """`parrot_voc_wait_stage` (ABI v7): a stage outside 0 .. n_stages - 1 is PARROT_E_INVALID; before the handle's first forward
+    there is nothing to wait for and the stream stays usable."""
+    from parrot_tts_amd import _lib
+    h = synth.small_voc_config()
+    g = _gen(h, synth.synth_voc_state_dict(h, seed=5))
+    b = synth.synth_voc_batch(2, 24, h, seed=1)
+    g(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV))  # builds the handle
+    st = torch.cuda.Stream(DEV)
+    lib = _lib.lib()
+    n_stages = len(h["upsample_rates"])
+    import ctypes as C
+    assert lib.parrot_voc_wait_stage(g._handle, -1, C.c_void_p(st.cuda_stream)) == -1
+    assert lib.parrot_voc_wait_stage(g._handle, n_stages, C.c_void_p(st.cuda_stream)) == -1
+    fresh = _gen(h, synth.synth_voc_state_dict(h, seed=5))
+    fresh.wait_stage(0, st)  # no handle yet: returns
+    for i in range(n_stages):
+        g.wait_stage(i, st)
+    with torch.cuda.stream(st):
+        y = g(code=b["code"].to(DEV), spkr=b["spkr"].to(DEV))
+    st.synchronize()
+    assert bool(torch.isfinite(y).all())
